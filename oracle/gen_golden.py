@@ -1,0 +1,599 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generate golden vectors by RUNNING the reference.
+
+Runs in the build container only (needs /root/reference).  Output: small .npz
+fixtures under tests/golden/ holding *data* (inputs, recorded RNG draws, outputs of
+the reference's IndustrialEnv.step / reset / evaluate_with_safety).  No reference
+source text is stored.  Re-run with:  python oracle/gen_golden.py
+
+Fixture families:
+  <env>_g1.npz  single-step tuples harvested from real rollouts under several policies
+  <env>_g2.npz  teacher-forced threshold / edge cases (one ulp either side of constants)
+  <env>_g3.npz  full rollouts (ragged, concatenated) with per-step outputs + episode sums
+  <env>_g4.npz  evaluate_with_safety() result dict for a fixed stub agent + its noise
+Reference semantics pinned: NumPy 2.2.6, float32 actions.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_import import NoiseTap, load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+ENVS = {"cr": "ChemicalReactor-v0", "pg": "PowerGrid-v0", "ra": "RobotAssembly-v0"}
+f32 = np.float32
+
+
+def ulp_step(x, k):
+    """k-th float32 neighbour of x (k may be negative)."""
+    x = f32(x)
+    for _ in range(abs(k)):
+        x = np.nextafter(x, f32(np.inf) if k > 0 else f32(-np.inf), dtype=f32)
+    return x
+
+
+class StepLog:
+    """Accumulates per-step tuples in the common fixture schema."""
+
+    def __init__(self, S, A, K):
+        self.S, self.A, self.K = S, A, K
+        self.rows = {k: [] for k in (
+            "state_pre", "action", "noise", "step_pre", "viol_pre", "state_next", "reward",
+            "terminated", "truncated", "viol", "crit", "bits", "violations_after")}
+
+    def add(self, **kw):
+        for k, v in kw.items():
+            self.rows[k].append(v)
+
+    def arrays(self):
+        r = self.rows
+        n = len(r["reward"])
+        return {
+            "state_pre": np.asarray(r["state_pre"], dtype=f32).reshape(n, self.S),
+            "action": np.asarray(r["action"], dtype=f32).reshape(n, self.A),
+            "noise": np.asarray(r["noise"], dtype=np.float64).reshape(n, self.K),
+            "step_pre": np.asarray(r["step_pre"], dtype=np.int32),
+            "viol_pre": np.asarray(r["viol_pre"], dtype=np.int32),
+            "state_next": np.asarray(r["state_next"], dtype=f32).reshape(n, self.S),
+            "reward": np.asarray(r["reward"], dtype=np.float64),
+            "terminated": np.asarray(r["terminated"], dtype=np.uint8),
+            "truncated": np.asarray(r["truncated"], dtype=np.uint8),
+            "viol": np.asarray(r["viol"], dtype=np.int32),
+            "crit": np.asarray(r["crit"], dtype=np.int32),
+            "bits": np.asarray(r["bits"], dtype=np.uint8).reshape(n, 3),
+            "violations_after": np.asarray(r["violations_after"], dtype=np.int32),
+        }
+
+
+def constraint_bits(env, state_pre, action_raw):
+    a = np.clip(action_raw, env.action_space.low, env.action_space.high)
+    return [1 if bool(c.check_fn(state_pre, a)) else 0 for c in env.safety_constraints]
+
+
+def do_step(env, tap, action, log, K):
+    """One reference env.step() with recording.  `action` must be float32."""
+    assert action.dtype == np.float32
+    state_pre = env.state.copy()
+    step_pre, viol_pre = env.current_step, env.violation_count
+    bits = constraint_bits(env, state_pre, action)
+    tap.take()
+    obs, reward, term, trunc, info = env.step(action)
+    noise = tap.take()
+    assert noise.size == K, (noise.size, K)
+    sm = info["safety_metrics"]
+    assert sm.violation_count == 3 - sum(bits)
+    log.add(state_pre=state_pre, action=action.copy(), noise=noise, step_pre=step_pre,
+            viol_pre=viol_pre, state_next=obs.copy(), reward=float(reward),
+            terminated=int(bool(term)), truncated=int(bool(trunc)),
+            viol=sm.violation_count, crit=sm.critical_violations, bits=bits,
+            violations_after=info["violations"])
+    return obs, reward, term, trunc, info
+
+
+def force(env, state, step=0, viol=0):
+    env.state = np.asarray(state, dtype=f32).copy()
+    env.current_step = int(step)
+    env.violation_count = int(viol)
+    env.done = False
+
+
+def forced_step(env, tap, state, action, noise, log, K, step=0, viol=0):
+    force(env, state, step, viol)
+    tap.forced = list(np.asarray(noise, dtype=np.float64).ravel())
+    try:
+        return do_step(env, tap, np.asarray(action, dtype=f32), log, K)
+    finally:
+        tap.forced = None
+
+
+# ----------------------------------------------------------------------------------
+# policies used to harvest G1 / G3 (all produce float32 actions)
+# ----------------------------------------------------------------------------------
+def make_policies(key, A, rng):
+    def uniform(obs):
+        return rng.uniform(-1, 1, A).astype(f32)
+
+    def zeros(obs):
+        return np.zeros(A, dtype=f32)
+
+    def wide(obs):  # exercises the clip at the Box bounds
+        return rng.uniform(-2.5, 2.5, A).astype(f32)
+
+    def bang(obs):
+        return np.where(rng.random(A) < 0.5, -1.0, 1.0).astype(f32)
+
+    pols = [("uniform", uniform), ("zeros", zeros), ("wide", wide), ("bang", bang)]
+    if key == "cr":
+        def hot(obs):
+            return np.array([1.0, -1.0, 1.0], dtype=f32)
+
+        def drain(obs):
+            return np.array([-0.2, 0.3, -1.0], dtype=f32)
+
+        def pid(obs):  # behaviour-policy shape of chemical_reactor.py get_dataset('expert'), cast f32
+            te = (obs[0] - f32(320.0)) / f32(50)
+            le = (obs[10] - f32(55)) / f32(50)
+            return np.array([-te * f32(0.5), te * f32(0.3), -le * f32(0.2)], dtype=f32) + \
+                rng.normal(0, 0.01, 3).astype(f32)
+        pols += [("hot", hot), ("drain", drain), ("pid", pid)]
+    if key == "pg":
+        def balance(obs):
+            imb = f32(np.sum(obs[17:25]) - np.sum(obs[9:17]))
+            return (f32(-0.5) * obs[0] * np.ones(A, dtype=f32) + f32(0.1) * imb / f32(A)).astype(f32)
+        pols += [("balance", balance)]
+    if key == "ra":
+        tgt = np.array([0.3, 0.0, 0.4], dtype=f32)
+
+        def reach(obs):
+            e = (tgt - obs[0:3]).astype(f32)
+            return np.concatenate([f32(2.0) * e, f32(-0.1) * obs[10:14]]).astype(f32)
+        pols += [("reach", reach)]
+    return pols
+
+
+def harvest_g1(utils, key, n_target, seed):
+    env = utils.make(ENVS[key])
+    S, A = env.state_dim, env.action_dim
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    pols = make_policies(key, A, rng)
+    with NoiseTap(seed) as tap:
+        env.reset()
+        K = None
+        # discover K (draws per step)
+        tap.take()
+        env.step(np.zeros(A, dtype=f32))
+        K = tap.take().size
+        log = StepLog(S, A, K)
+        per = n_target // len(pols)
+        for name, pol in pols:
+            got = 0
+            while got < per:
+                obs, _ = env.reset()
+                tap.take()
+                done = False
+                while not done and got < per:
+                    obs, r, te, tr, info = do_step(env, tap, pol(obs), log, K)
+                    done = te or tr
+                    got += 1
+    return log.arrays(), K
+
+
+# ----------------------------------------------------------------------------------
+# G2: teacher-forced edge cases
+# ----------------------------------------------------------------------------------
+def g2_cr(utils, seed):
+    env = utils.make(ENVS["cr"])
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K = 2
+    log = StepLog(12, 3, K)
+    nominal = np.array([320, 253312.5, 50, 30, 0.5, 95, 295, 0, 0, 0, 60, 0], dtype=f32)
+
+    def base():
+        s = nominal.copy()
+        s[[0, 2, 3, 4, 5, 6, 10]] += rng.normal(0, [1, 2, 1, 0.05, 1, 0.5, 2]).astype(f32)
+        return s
+
+    def act():
+        return rng.uniform(-1, 1, 3).astype(f32)
+
+    with NoiseTap(seed) as tap:
+        env.reset()
+
+        def go(s, a=None, noise=(0.0, 0.0), step=0, viol=0):
+            return forced_step(env, tap, s, act() if a is None else a, noise, log, K, step, viol)
+
+        # (a) constraint thresholds on the pre-state
+        for idx, thr in ((0, 350.0), (1, 506625.0), (10, 20.0), (10, 90.0)):
+            for k in (-2, -1, 0, 1, 2):
+                s = base(); s[idx] = ulp_step(thr, k); go(s)
+        # level thresholds seen by reward / is_done on the NEXT state: feed'=20 -> level'=level
+        for thr in (5.0, 95.0, 30.0, 80.0, 0.0, 100.0):
+            for k in (-2, -1, 0, 1, 2):
+                s = base(); s[3] = 20.0; s[10] = ulp_step(thr, k)
+                go(s, np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 0.0], dtype=f32))
+        # (b) e-stop / alarm pass-through thresholds, e-stop mode dynamics
+        for v in (ulp_step(0.5, -1), f32(0.5), ulp_step(0.5, 1), f32(1.0), f32(0.25)):
+            for _ in range(4):
+                s = base(); s[8] = v; go(s, noise=rng.normal(0, [0.1, 500]))
+                s = base(); s[9] = v; go(s, noise=rng.normal(0, [0.1, 500]))
+                s = base(); s[8] = v; s[9] = 1.0; go(s)
+        # (c) relief valve + pressure floor (Python min/max int leakage paths)
+        for rel in (0.0, 1e-3, 50.0, 99.9, 100.0, 150.0, -5.0):
+            for P in (101325.0, 150000.0, 253312.5, 480000.0, 506000.0, 506625.0, 507000.0,
+                      520000.0, 606625.0, 706625.0, 110000.0):
+                s = base(); s[7] = rel; s[1] = P; go(s, noise=(0.0, float(rng.normal(0, 500))))
+        # (d) flow clamps
+        for cool in (10.0, 10.05, 10.1, 99.9, 99.95, 100.0, 5.0, 120.0):
+            for a1 in (-1.0, 1.0, 0.0):
+                s = base(); s[2] = cool; go(s, np.array([0.1, a1, 0.0], dtype=f32))
+        for feed in (5.0, 5.05, 5.1, 49.9, 49.95, 50.0, 2.0, 60.0, 20.0):
+            for a2 in (-1.0, 1.0, 0.0):
+                s = base(); s[3] = feed; go(s, np.array([0.0, 0.2, a2], dtype=f32))
+        # (e) concentration floor, catalyst floor
+        for conc in (0.0, 1e-4, 2e-3, -0.01, 3e-3, 5.0):
+            for feed in (5.0, 30.0, 50.0):
+                s = base(); s[4] = conc; s[3] = feed; go(s)
+        for cat in (50.0, 50.00005, 50.0005, 50.002, 49.0, 100.0):
+            for T in (330.0, 341.0):
+                s = base(); s[5] = cat; s[0] = T; go(s)
+        # (f) next-state temperature thresholds 340 / 345 / 350, dense in ulps
+        for thr in (340.0, 345.0, 350.0):
+            for k in range(-12, 13):
+                s = base(); s[0] = f32(thr - 0.05); a = act()
+                force(env, s); tap.forced = [0.0, 0.0]
+                o0 = env.step(a)[0]; tap.forced = None; tap.take()
+                target = float(ulp_step(thr, k))
+                n0 = (target - float(o0[0])) / 0.1
+                go(s, a, noise=(n0, float(rng.normal(0, 500))))
+        # (g) next-state pressure thresholds 480000 / 506625
+        for thr in (480000.0, 506625.0):
+            for k in range(-12, 13):
+                s = base(); s[1] = f32(thr - 2000.0); a = act()
+                n0 = float(rng.normal(0, 0.1))
+                force(env, s); tap.forced = [n0, 0.0]
+                o0 = env.step(a)[0]; tap.forced = None; tap.take()
+                # relief not active below 506625 so P' is linear in n1 there
+                target = float(ulp_step(thr, k))
+                n1 = target - float(o0[1])
+                go(s, a, noise=(n0, n1))
+        # (h) batch time limit
+        for k in range(-6, 7):
+            s = base(); s[11] = ulp_step(49.9, k); go(s)
+        for bt in (49.7, 49.8, 50.0, 50.1, 0.0):
+            s = base(); s[11] = bt; go(s)
+        # (i) truncation boundary + running violation counter
+        for step in (0, 1, 497, 498, 499):
+            s = base(); go(s, step=step, viol=step // 7)
+            s = base(); s[10] = 15.0; go(s, step=step, viol=3)
+            s = base(); s[0] = 351.0; s[1] = 510000.0; s[10] = 95.5; go(s, step=step, viol=11)
+        # (j) actions outside the Box (clip) incl. exact bounds
+        for a in ([1.0, -1.0, 1.0], [1.5, -3.0, 7.0], [-1.0000001, 1.0000001, 0.0], [0, 0, 0]):
+            s = base(); go(s, np.array(a, dtype=f32), noise=rng.normal(0, [0.1, 500]))
+        # (k) random broad states (both modes) for general coverage
+        for _ in range(600):
+            s = base()
+            s[0] = rng.uniform(300, 356); s[1] = rng.uniform(9e4, 5.3e5)
+            s[2] = rng.uniform(8, 102); s[3] = rng.uniform(4, 52); s[4] = rng.uniform(-0.05, 1.5)
+            s[5] = rng.uniform(49, 100); s[6] = rng.uniform(285, 305)
+            s[7] = rng.choice([0.0, 0.0, rng.uniform(0, 100)])
+            s[8] = rng.choice([0.0, 0.0, 0.0, 1.0]); s[9] = rng.choice([0.0, 1.0])
+            s[10] = rng.uniform(0, 100); s[11] = rng.uniform(0, 50.2)
+            go(s, rng.uniform(-1.3, 1.3, 3).astype(f32), noise=rng.normal(0, [0.1, 500]),
+               step=int(rng.integers(0, 500)), viol=int(rng.integers(0, 50)))
+    return log.arrays(), K
+
+
+def g2_pg(utils, seed):
+    env = utils.make(ENVS["pg"])
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K = 23
+    log = StepLog(32, 8, K)
+    base_load = np.array([50, 60, 45, 55, 40, 65, 35, 50], dtype=f32)
+
+    def base():
+        s = np.zeros(32, dtype=f32)
+        s[1:9] = 1.0 + rng.normal(0, 0.01, 8)
+        s[9:17] = base_load + rng.normal(0, 2, 8)
+        s[17:25] = base_load * (1.0 + rng.uniform(-0.2, 0.2, 8))
+        s[25:32] = rng.normal(0, 10, 7)
+        return s
+
+    def act():
+        return rng.uniform(-1, 1, 8).astype(f32)
+
+    def noise(scale=1.0):
+        return np.concatenate([rng.normal(0, 0.005, 8), rng.normal(0, 1, 8), rng.normal(0, 2, 7)]) * scale
+
+    with NoiseTap(seed) as tap:
+        env.reset()
+
+        def go(s, a=None, nz=None, step=0, viol=0):
+            return forced_step(env, tap, s, act() if a is None else a,
+                               np.zeros(K) if nz is None else nz, log, K, step, viol)
+
+        # (a) frequency thresholds 0.5 (constraint, pre) and 1.0 (is_done, post; imbalance == f keeps f'=f)
+        for sign in (1.0, -1.0):
+            for thr in (0.5, 1.0, 0.25):
+                for k in (-2, -1, 0, 1, 2):
+                    s = base(); f = ulp_step(sign * thr, k)
+                    s[0] = f; s[9:17] = base_load; s[17:25] = base_load; s[17] = f32(50.0) - f
+                    go(s, np.zeros(8, dtype=f32))
+                    s = base(); s[0] = f; go(s, nz=noise())
+        # (b) voltage thresholds (pre-state constraint 0.95/1.05, next-state is_done 0.9/1.1)
+        for thr in (0.95, 1.05, 0.9, 1.1):
+            for k in (-2, -1, 0, 1, 2):
+                for bus in (0, 3, 7):
+                    s = base(); s[1 + bus] = ulp_step(thr, k); go(s)
+                s = base(); s[1:9] = ulp_step(thr, k); go(s)
+        for thr in (0.9, 1.1):  # crossing via the fp64 noise add
+            for d in (-3e-8, -1e-8, 0.0, 1e-8, 3e-8, 6e-8, -6e-8):
+                s = base(); s[4] = f32(1.0); nz = np.zeros(K); nz[3] = (thr - 1.0) + d; go(s, nz=nz)
+        # (c) generation limits 0 / 100 (constraint uses gen + clipped action; dynamics clip)
+        for g, a in ((99.5, 0.5), (99.75, 0.5), (100.0, 0.0), (100.0, 1.0), (0.25, -0.5), (0.5, -0.5),
+                     (0.0, 0.0), (0.0, -1.0), (99.0, 3.0), (1.0, -3.0), (100.5, -0.25), (-0.5, 0.25)):
+            for unit in (0, 5):
+                s = base(); s[9 + unit] = g; av = act(); av[unit] = a; go(s, av, noise())
+        # (d) load floor at zero through the fp64 add
+        for ld, nl in ((0.5, -0.5), (0.5, -0.75), (0.25, -0.2499999), (0.0, 0.0), (1e-3, -2e-3), (3.0, -2.0)):
+            s = base(); s[17 + 2] = ld; nz = noise(); nz[8 + 2] = nl; go(s, nz=nz)
+        # (e) truncation boundary (default max_episode_steps = 1000)
+        for step in (0, 997, 998, 999):
+            s = base(); go(s, nz=noise(), step=step, viol=step // 100)
+            s = base(); s[0] = 0.7; go(s, nz=noise(), step=step, viol=2)
+        # (f) clip of the action
+        for a in (np.full(8, 1.0), np.full(8, -1.0), rng.uniform(-4, 4, 8), np.full(8, 1.0000001)):
+            s = base(); go(s, a.astype(f32), noise())
+        # (g) broad random states
+        for _ in range(500):
+            s = base()
+            s[0] = rng.uniform(-1.2, 1.2)
+            s[1:9] = rng.uniform(0.88, 1.12, 8) if rng.random() < 0.5 else s[1:9]
+            s[9:17] = rng.uniform(-2, 103, 8) if rng.random() < 0.5 else s[9:17]
+            s[17:25] = rng.uniform(0, 90, 8)
+            go(s, rng.uniform(-1.5, 1.5, 8).astype(f32), noise(rng.choice([1.0, 3.0])),
+               step=int(rng.integers(0, 1000)), viol=int(rng.integers(0, 9)))
+    return log.arrays(), K
+
+
+def _ra_fk(q):
+    L = [0.3, 0.3, 0.25, 0.25, 0.15, 0.1, 0.05]
+    x = sum(L[i] * math.cos(q[i]) for i in (0, 2, 4, 6))
+    z = sum(L[i] * math.sin(q[i]) for i in (0, 2, 4, 6))
+    y = sum(L[i] * math.sin(q[i]) for i in (1, 3, 5))
+    return x, y, z
+
+
+def g2_ra(utils, seed):
+    env = utils.make(ENVS["ra"])
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K = 0
+    log = StepLog(24, 7, K)
+
+    def state_from_q(q):
+        s = np.zeros(24, dtype=f32)
+        s[0:3] = _ra_fk(q); s[3:7] = [0, 0, 0, 1]; s[7:14] = q
+        return s
+
+    def base():
+        return state_from_q(rng.uniform(-math.pi / 2, math.pi / 2, 7))
+
+    def act():
+        return rng.uniform(-1, 1, 7).astype(f32)
+
+    with NoiseTap(seed) as tap:
+        env.reset(); tap.take()
+
+        def go(s, a=None, step=0, viol=0):
+            return forced_step(env, tap, s, act() if a is None else a, [], log, K, step, viol)
+
+        # (a) pre-state constraint thresholds
+        for comp in (18, 19, 20):
+            for thr in (50.0, -50.0, 30.0, 80.0, -80.0):
+                for k in (-1, 0, 1):
+                    s = base(); s[comp] = ulp_step(thr, k); go(s)
+        for comp, thrs in ((0, (-0.5, 0.5, -0.6, 0.6)), (1, (-0.5, 0.5)), (2, (0.0, 0.8, -0.1, 0.9))):
+            for thr in thrs:
+                for k in (-2, -1, 0, 1, 2):
+                    s = base(); s[comp] = ulp_step(thr, k); go(s)
+        for j in (0, 3, 6):
+            for thr in (2.0, -2.0):
+                for k in (-1, 0, 1):
+                    s = base(); s[7 + j] = ulp_step(thr, k); go(s)
+        # (b) joint limit clip at +-pi (f32(pi) > pi: stored value exceeds the f64 limit)
+        for qv in (3.1, 3.14, 3.1415927, 3.2, -3.1, -3.1415927, -3.3, 3.0415927):
+            for a0 in (1.0, -1.0, 0.0):
+                s = base(); s[7 + 2] = qv; a = act(); a[2] = a0; go(s, a)
+        # (c) next-state workspace exit (is_done) and in-bounds cases
+        for q in ([0, 0, 0, 0, 0, 0, 0], [0.3, 0, -0.3, 0, 0.2, 0, 0.1], [1.2, 0.2, 1.0, -0.3, 0.8, 0.1, 0.5],
+                  [-1.2, 1.5, -1.0, 1.5, -0.8, 1.5, -0.5], [1.5, -1.5, 1.5, -1.5, 1.5, -1.5, 1.5]):
+            go(state_from_q(np.array(q, dtype=np.float64)), np.zeros(7, dtype=f32))
+            go(state_from_q(np.array(q, dtype=np.float64)))
+        # (d) completion > 0.95:  q0=pi/2, q2=0, q4=-pi/2, q6=0 -> p=(0.30, 0, 0.15)
+        qc = np.array([math.pi / 2, 0, 0, 0, -math.pi / 2, 0, 0.0])
+        for d6 in (0.0, 1e-3, 5e-3, 2e-2, 5e-2, 9e-2, 0.1, 0.12):
+            q = qc.copy(); q[6] = d6
+            go(state_from_q(q), np.zeros(7, dtype=f32))
+        for dz in (0.0, 0.2, 0.3, 0.33, 0.34):  # depth score between 0 and 1
+            q = qc.copy(); q[4] = -math.pi / 2 + dz * 4
+            go(state_from_q(q), np.zeros(7, dtype=f32))
+        # (e) contact spring: reach p=(0.3,0,0.4) with the last two even links (2-link IK)
+        x, z, l1, l2 = 0.05, 0.10, 0.15, 0.05
+        c2 = (x * x + z * z - l1 * l1 - l2 * l2) / (2 * l1 * l2)
+        th2 = math.acos(c2)
+        th1 = math.atan2(z, x) - math.atan2(l2 * math.sin(th2), l1 + l2 * math.cos(th2))
+        qk = np.array([math.pi / 2, 0, 0, 0, th1, 0, th1 + th2])
+        for dq in (0.0, 1e-3, 1e-2, 3e-2, 6e-2, 0.1, 0.15, 0.19, 0.2, 0.21, 0.25, -0.05, -0.2):
+            q = qk.copy(); q[6] += dq
+            go(state_from_q(q), np.zeros(7, dtype=f32))
+            q = qk.copy(); q[1] = dq * 0.1
+            go(state_from_q(q), np.zeros(7, dtype=f32))
+        # (f) truncation boundary
+        for step in (0, 997, 998, 999):
+            q = np.array([1.4, 0.1, 1.3, -0.1, 1.2, 0.05, 1.0])  # inside workspace
+            go(state_from_q(q), step=step, viol=step // 50)
+        # (g) clip of the action
+        for a in (np.full(7, 1.0), np.full(7, -1.0), rng.uniform(-4, 4, 7), np.full(7, -1.0000001)):
+            go(base(), a.astype(f32))
+        # (h) broad random (pre-state position decoupled from q on purpose: velocity term)
+        for _ in range(500):
+            s = base()
+            if rng.random() < 0.5:
+                s[0:3] += rng.normal(0, 0.05, 3).astype(f32)
+            if rng.random() < 0.3:
+                s[7:14] = rng.uniform(-3.3, 3.3, 7)
+            if rng.random() < 0.2:
+                s[18:21] = rng.uniform(-90, 90, 3)
+            s[14:18] = rng.normal(0, 1, 4); s[21:24] = rng.uniform(0, 1, 3)
+            go(s, rng.uniform(-1.5, 1.5, 7).astype(f32), step=int(rng.integers(0, 1000)),
+               viol=int(rng.integers(0, 9)))
+    return log.arrays(), K
+
+
+# ----------------------------------------------------------------------------------
+# G3 rollouts / G4 evaluate_with_safety
+# ----------------------------------------------------------------------------------
+class StubAgent:
+    """Fixed elementwise policy: a_j = clip(k_j * (obs[i_j] - c_j), -1, 1) in float32.
+
+    One subtract + one multiply per action => IEEE-exact, reproducible on any host.
+    The same parameters are re-created in tests/ from the values stored in the fixture.
+    """
+    is_trained = True
+
+    def __init__(self, idx, ref, gain):
+        self.idx = np.asarray(idx, dtype=np.int64)
+        self.ref = np.asarray(ref, dtype=f32)
+        self.gain = np.asarray(gain, dtype=f32)
+        self.trace = []
+
+    def predict(self, obs, deterministic=True):
+        obs = np.asarray(obs, dtype=f32)
+        a = np.clip((obs[:, self.idx] - self.ref) * self.gain, f32(-1), f32(1)).astype(f32)
+        self.trace.append(a[0].copy())
+        return a
+
+
+STUB = {
+    "cr": dict(idx=[0, 0, 10], ref=[320.0, 320.0, 55.0], gain=[-0.05, 0.03, -0.02]),
+    "pg": dict(idx=[0] * 8, ref=[0.0] * 8, gain=[-0.5, -0.4, -0.3, -0.2, -0.5, -0.4, -0.3, -0.2]),
+    "ra": dict(idx=[0, 1, 2, 7, 8, 9, 10], ref=[0.3, 0.0, 0.4, 0, 0, 0, 0],
+               gain=[-2.0, -2.0, -2.0, -0.1, -0.1, -0.1, -0.1]),
+}
+
+
+def record_rollouts(utils, key, n_episodes, seed, policy_name, KR, K, use_eval=False):
+    env = utils.make(ENVS[key])
+    S, A = env.state_dim, env.action_dim
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    ep = dict(init_noise=[], init_state=[], length=[], ret=[], viol=[], crit=[], shut=[], term_last=[],
+              trunc_last=[])
+    st = dict(action=[], noise=[], obs=[], reward=[], term=[], trunc=[], viol=[], crit=[])
+    agent = StubAgent(**STUB[key])
+    result = None
+    with NoiseTap(seed) as tap:
+        orig_reset, orig_step = env.reset, env.step
+
+        def reset(**kw):
+            tap.take()
+            obs, info = orig_reset(**kw)
+            n = tap.take(); assert n.size == KR
+            ep["init_noise"].append(n); ep["init_state"].append(obs.copy())
+            for k in ("length", "viol", "crit", "shut"):
+                ep[k].append(0)
+            ep["ret"].append(0.0)
+            ep["term_last"].append(0); ep["trunc_last"].append(0)
+            return obs, info
+
+        def step(action):
+            action = np.asarray(action, dtype=f32)
+            tap.take()
+            obs, r, te, tr, info = orig_step(action)
+            n = tap.take(); assert n.size == K
+            sm = info["safety_metrics"]
+            st["action"].append(action.copy()); st["noise"].append(n); st["obs"].append(obs.copy())
+            st["reward"].append(float(r)); st["term"].append(int(bool(te))); st["trunc"].append(int(bool(tr)))
+            st["viol"].append(sm.violation_count); st["crit"].append(sm.critical_violations)
+            ep["length"][-1] += 1
+            ep["ret"][-1] = ep["ret"][-1] + r      # same accumulation expression as utils.py:99
+            ep["viol"][-1] += sm.violation_count; ep["crit"][-1] += sm.critical_violations
+            ep["shut"][-1] += int(bool(info["critical_shutdown"]))
+            ep["term_last"][-1] = int(bool(te)); ep["trunc_last"][-1] = int(bool(tr))
+            return obs, r, te, tr, info
+
+        env.reset, env.step = reset, step
+        if use_eval:
+            result = utils.evaluate_with_safety(agent, env, n_episodes=n_episodes)
+        else:
+            pols = dict(make_policies(key, A, rng))
+            pol = pols[policy_name]
+            for _ in range(n_episodes):
+                obs, _ = env.reset()
+                done = False
+                while not done:
+                    obs, r, te, tr, info = env.step(pol(obs))
+                    done = te or tr
+    n = len(st["reward"])
+    E = len(ep["length"])
+    out = {
+        "ep_init_noise": np.asarray(ep["init_noise"], dtype=np.float64).reshape(E, KR),
+        "ep_init_state": np.asarray(ep["init_state"], dtype=f32).reshape(E, S),
+        "ep_length": np.asarray(ep["length"], dtype=np.int32),
+        "ep_return": np.asarray([float(x) for x in ep["ret"]], dtype=np.float64),
+        "ep_viol": np.asarray(ep["viol"], dtype=np.int64),
+        "ep_crit": np.asarray(ep["crit"], dtype=np.int64),
+        "ep_shutdown": np.asarray(ep["shut"], dtype=np.int64),
+        "ep_offsets": np.concatenate([[0], np.cumsum(ep["length"])]).astype(np.int64),
+        "action": np.asarray(st["action"], dtype=f32).reshape(n, A),
+        "noise": np.asarray(st["noise"], dtype=np.float64).reshape(n, K),
+        "obs": np.asarray(st["obs"], dtype=f32).reshape(n, S),
+        "reward": np.asarray(st["reward"], dtype=np.float64),
+        "terminated": np.asarray(st["term"], dtype=np.uint8),
+        "truncated": np.asarray(st["trunc"], dtype=np.uint8),
+        "viol": np.asarray(st["viol"], dtype=np.int32),
+        "crit": np.asarray(st["crit"], dtype=np.int32),
+    }
+    if result is not None:
+        out["result_json"] = np.frombuffer(json.dumps(
+            {k: float(v) for k, v in result.items()}, sort_keys=True).encode(), dtype=np.uint8)
+        for k in ("idx", "ref", "gain"):
+            out["agent_" + k] = np.asarray(STUB[key][k], dtype=np.float64)
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    utils = load_reference()
+    meta = {"numpy": np.__version__, "envs": ENVS}
+    KR = {"cr": 8, "pg": 31, "ra": 7}
+    g2 = {"cr": g2_cr, "pg": g2_pg, "ra": g2_ra}
+    g1_target = {"cr": 4200, "pg": 2500, "ra": 2500}
+    g3_eps = {"cr": 12, "pg": 64, "ra": 64}
+    for key in ENVS:
+        arr, K = harvest_g1(utils, key, g1_target[key], seed=1000 + len(key) + ord(key[0]))
+        np.savez_compressed(os.path.join(OUT, f"{key}_g1.npz"), **arr)
+        print(key, "g1", arr["reward"].shape[0], "K", K,
+              "crit>0:", int((arr["crit"] > 0).sum()), "term:", int(arr["terminated"].sum()))
+        arr2, K2 = g2[key](utils, seed=2000 + ord(key[0]))
+        assert K2 == K
+        np.savez_compressed(os.path.join(OUT, f"{key}_g2.npz"), **arr2)
+        print(key, "g2", arr2["reward"].shape[0], "crit>0:", int((arr2["crit"] > 0).sum()),
+              "term:", int(arr2["terminated"].sum()), "trunc:", int(arr2["truncated"].sum()))
+        g3 = record_rollouts(utils, key, g3_eps[key], 3000 + ord(key[0]), "uniform", KR[key], K)
+        np.savez_compressed(os.path.join(OUT, f"{key}_g3.npz"), **g3)
+        print(key, "g3 episodes", g3["ep_length"].size, "steps", g3["reward"].size,
+              "len min/mean/max", g3["ep_length"].min(), g3["ep_length"].mean(), g3["ep_length"].max())
+        g4 = record_rollouts(utils, key, 20, 4000 + ord(key[0]), None, KR[key], K, use_eval=True)
+        np.savez_compressed(os.path.join(OUT, f"{key}_g4.npz"), **g4)
+        print(key, "g4 steps", g4["reward"].size, bytes(g4["result_json"]).decode())
+        meta[key] = {"K_step": K, "K_reset": KR[key]}
+    with open(os.path.join(OUT, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,758 @@
+/*
+ * nig_oracle.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+ *
+ * A scalar, plain-C CPU restatement of the reference's NumPy hot path
+ * (danieleschmidt/neoRL-industrial-gym, IndustrialEnv.step / reset and the three
+ * working environments).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (libnig.so) never does.
+ *
+ * Parity pin: checked bit-for-bit / within 1e-5 against golden vectors produced by
+ * RUNNING the reference in the build container (oracle/gen_golden.py ->
+ * tests/golden/ (npz); NumPy 2.2.6 semantics, float32 actions).  See
+ * tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/neorl_industrial/).  Arithmetic notes (NEP-50 weak scalars,
+ * Python min/max first-argument-wins, NumPy pairwise 8-sum) are from SURVEY.md
+ * Appendix A and were re-verified against the goldens.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_CR 0
+#define ORACLE_PG 1
+#define ORACLE_RA 2
+
+#define MATH_LIBM 0 /* libm expf / sin / cos                    */
+#define MATH_POLY 1 /* documented polynomials (DESIGN.md "detmath"), bitwise = device */
+
+/* ------------------------------------------------------------------------------
+ * detmath: polynomial exp/log/sincos written ONLY with IEEE + - * / (no fma, no
+ * libm) so that a CPU and a GPU evaluation agree bit-for-bit.  Specification in
+ * DESIGN.md section "Deterministic math".  Coefficients are the classic Cephes
+ * single-precision / fdlibm double-precision minimax sets.
+ * ---------------------------------------------------------------------------- */
+static float det_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283f) return INFINITY;
+    if (x < -103.0f) return 0.0f;
+    float fk = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - fk * 0.693359375f;
+    r = r - fk * -2.12194440e-4f;
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r;
+    p = p + 1.0f;
+    int k = (int)fk;
+    /* scale by 2^k in two exact steps so that subnormal results round once */
+    int k1 = k / 2, k2 = k - k1;
+    union { uint32_t u; float f; } s1, s2;
+    s1.u = (uint32_t)(k1 + 127) << 23;
+    s2.u = (uint32_t)(k2 + 127) << 23;
+    return (p * s1.f) * s2.f;
+}
+
+/* natural log of a float in (0, 1] (normal numbers only; callers pass k*2^-24, k>=1) */
+static float det_logf(float x)
+{
+    union { float f; uint32_t u; } v; v.f = x;
+    int e = (int)(v.u >> 23) - 126;                  /* x = m * 2^e, m in [0.5,1) */
+    v.u = (v.u & 0x007fffffu) | 0x3f000000u;
+    float m = v.f;
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = y * m + -1.1514610310e-1f;
+    y = y * m + 1.1676998740e-1f;
+    y = y * m + -1.2420140846e-1f;
+    y = y * m + 1.4249322787e-1f;
+    y = y * m + -1.6668057665e-1f;
+    y = y * m + 2.0000714765e-1f;
+    y = y * m + -2.4999993993e-1f;
+    y = y * m + 3.3333331174e-1f;
+    y = y * m * z;
+    float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    float r = m + y;
+    r = r + 0.693359375f * fe;
+    return r;
+}
+
+/* sin and cos of 2*pi*k/2^24 for a 24-bit integer k (exact octant reduction) */
+static void det_sincos2pi_u24(uint32_t k, float *s, float *c)
+{
+    uint32_t oct = (k >> 21) & 7u;
+    uint32_t frac = k & 0x1fffffu;
+    if (oct & 1u) frac = 0x200000u - frac;           /* reflect inside odd octants */
+    float x = (float)frac * (0.78539816339744830962f / 2097152.0f); /* [0, pi/4] */
+    float z = x * x;
+    float sp = -1.9515295891e-4f;
+    sp = sp * z + 8.3321608736e-3f;
+    sp = sp * z + -1.6666654611e-1f;
+    sp = sp * z * x + x;
+    float cp = 2.443315711809948e-5f;
+    cp = cp * z + -1.388731625493765e-3f;
+    cp = cp * z + 4.166664568298827e-2f;
+    cp = cp * z * z;
+    cp = cp + -0.5f * z;
+    cp = cp + 1.0f;
+    float ss, cc;
+    switch (oct) {
+    case 0: ss = sp;  cc = cp;  break;
+    case 1: ss = cp;  cc = sp;  break;
+    case 2: ss = cp;  cc = -sp; break;
+    case 3: ss = sp;  cc = -cp; break;
+    case 4: ss = -sp; cc = -cp; break;
+    case 5: ss = -cp; cc = -sp; break;
+    case 6: ss = -cp; cc = sp;  break;
+    default: ss = -sp; cc = cp; break;
+    }
+    *s = ss; *c = cc;
+}
+
+/* double sin/cos for moderate |x| (joint angles, |x| <= ~1e3): Cody-Waite + fdlibm kernels */
+static void det_sincos(double x, double *s, double *c)
+{
+    double fk = floor(x * 0.63661977236758134308 + 0.5);
+    double r = x - fk * 1.57079632673412561417e+00;
+    r = r - fk * 6.07710050650619224932e-11;
+    double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z + -2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z + -1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z + -1.66666666666666324348e-01;
+    double sn = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z + -2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z + -1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    double cs = 1.0 - 0.5 * z + z * z * pc;
+    long long q = (long long)fk;
+    switch ((int)(q & 3)) {
+    case 0: *s = sn;  *c = cs;  break;
+    case 1: *s = cs;  *c = -sn; break;
+    case 2: *s = -sn; *c = -cs; break;
+    default: *s = -cs; *c = sn; break;
+    }
+}
+
+static float o_expf(float x, int flavor) { return flavor == MATH_POLY ? det_expf(x) : expf(x); }
+static void o_sincos(double x, int flavor, double *s, double *c)
+{
+    if (flavor == MATH_POLY) { det_sincos(x, s, c); } else { *s = sin(x); *c = cos(x); }
+}
+
+/* Python's builtin max(a, b) / min(a, b): "b if b > a else a" / "b if b < a else a"
+ * (first argument wins ties and NaNs).  Used wherever the reference calls builtin
+ * min/max on scalars, e.g. chemical_reactor.py:166-167,175-176,186-187,195,216. */
+static float pymaxf(float a, float b) { return (b > a) ? b : a; }
+static float pyminf(float a, float b) { return (b < a) ? b : a; }
+static double pymaxd(double a, double b) { return (b > a) ? b : a; }
+static double pymind(double a, double b) { return (b < a) ? b : a; }
+
+/* NumPy add.reduce over exactly 8 contiguous elements: 8 accumulators then the tree
+ * ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))  (numpy pairwise_sum, n == 8). */
+static float sum8f(const float *x) { return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])); }
+static double sum8d(const double *x) { return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])); }
+
+/* ------------------------------------------------------------------------------
+ * environment tables  (base.py:22-72 ctor; per-env ctor constants)
+ * ---------------------------------------------------------------------------- */
+typedef struct {
+    int state_dim, action_dim, n_constraints;
+    int k_step, k_reset;          /* RNG draws per step / per reset, in reference call order */
+    int max_episode_steps;        /* default */
+    double dt;                    /* default */
+    double penalty[3];
+    int critical[3];
+} oracle_spec_t;
+
+static const oracle_spec_t SPECS[3] = {
+    /* chemical_reactor.py:38-69 */ {12, 3, 3, 2, 8, 500, 0.1, {-100.0, -50.0, -25.0}, {1, 1, 0}},
+    /* power_grid.py:53-79       */ {32, 8, 3, 23, 31, 1000, 0.1, {-50.0, -30.0, -20.0}, {1, 1, 0}},
+    /* robot_assembly.py:56-82   */ {24, 7, 3, 0, 7, 1000, 0.1, {-100.0, -200.0, -50.0}, {1, 1, 0}},
+};
+
+int oracle_spec(int env, oracle_spec_t *out)
+{
+    if (env < 0 || env > 2) return -1;
+    *out = SPECS[env];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------
+ * ChemicalReactor-v0   (chemical_reactor.py)
+ * ---------------------------------------------------------------------------- */
+/* _get_initial_state, chemical_reactor.py:89-107: fp64 sums, stored float32 */
+static void cr_reset(const double *n, float *s)
+{
+    s[0] = (float)(320.0 + n[0]);
+    s[1] = (float)(253312.5 + n[1]);
+    s[2] = (float)(50.0 + n[2]);
+    s[3] = (float)(30.0 + n[3]);
+    s[4] = (float)(0.5 + n[4]);
+    s[5] = (float)(95.0 + n[5]);
+    s[6] = (float)(295.0 + n[6]);
+    s[7] = 0.0f; s[8] = 0.0f; s[9] = 0.0f;
+    s[10] = (float)(60.0 + n[7]);
+    s[11] = 0.0f;
+}
+
+/* _dynamics, chemical_reactor.py:109-226.  All float32 (float32 action, NumPy>=2). */
+static void cr_dynamics(const float *s, const float *a, const double *noise, int flavor, float *o)
+{
+    float temp = s[0], pressure = s[1], cool = s[2], feed = s[3], conc = s[4], cat = s[5];
+    float hx = s[6], relief = s[7], estop = s[8], alarm = s[9], level = s[10], bt = s[11];
+    float hp, cadj, fadj;
+    if (estop < 0.5f) {                                        /* :126-134 */
+        hp = a[0] * 50000.0f; cadj = a[1] * 0.1f; fadj = a[2] * 0.1f;
+    } else {
+        hp = -10000.0f; cadj = 0.1f; fadj = -0.1f;
+    }
+    float rh = ((0.1f * conc) * (cat / 100.0f)) * 10000.0f;    /* :137-140 */
+    float ch = ((cool * 100.0f) * (temp - hx)) * 0.1f;         /* :141 */
+    float dT = ((hp + rh) - ch) / 418000.0f;                   /* :143-146 */
+    dT = dT + (float)noise[0];                                 /* :149 */
+    float nT = temp + dT * 0.1f;                               /* :151 */
+    float pft = pressure * (nT / temp);                        /* :155 */
+    float pfr = (conc * 0.1f) * 1000.0f;                       /* :156 */
+    float nP = pft + pfr * 0.1f;                               /* :158 */
+    nP = nP + (float)noise[1];                                 /* :159 */
+    float nrel = pymaxf(0.0f, pyminf(100.0f, relief + (nP - 506625.0f) * 0.001f)); /* :162-163 */
+    if (nrel > 0.0f) {                                         /* :166-168 */
+        float pr = (nrel * 0.01f) * 10000.0f;
+        nP = pymaxf(101325.0f, nP - pr);
+    }
+    float ncool = pymaxf(10.0f, pyminf(100.0f, cool + cadj));  /* :171 */
+    float nfeed = pymaxf(5.0f, pyminf(50.0f, feed + fadj));    /* :172 */
+    float rr = ((0.1f * conc) * (cat / 100.0f)) * o_expf((-(nT - 320.0f)) / 20.0f, flavor); /* :175-178 */
+    float fd = nfeed * 0.001f;                                 /* :180 */
+    float nconc = pymaxf(0.0f, conc + (rr - fd) * 0.1f);       /* :181-182 */
+    float deact = (nT > 340.0f) ? 0.001f : 0.0001f;            /* :185 */
+    float ncat = pymaxf(50.0f, cat - deact);                   /* :186 */
+    float nhx = hx + (0.1f * ((290.0f + cool * 0.1f) - hx)) * 0.1f; /* :189-190 */
+    float nestop = estop, nalarm = alarm;                      /* :193-194 */
+    if (nT > 345.0f || nP > 480000.0f) nalarm = 1.0f;          /* :196-197 */
+    if (nT > 350.0f || nP > 506625.0f) { nestop = 1.0f; nalarm = 1.0f; } /* :199-201 */
+    float lc = (nfeed - 20.0f) * 0.1f;                         /* :204 */
+    float nlevel = pymaxf(0.0f, pyminf(100.0f, level + lc * 0.1f)); /* :205 */
+    float nbt = bt + 0.1f;                                     /* :208 */
+    o[0] = nT; o[1] = nP; o[2] = ncool; o[3] = nfeed; o[4] = nconc; o[5] = ncat; o[6] = nhx;
+    o[7] = nrel; o[8] = nestop; o[9] = nalarm; o[10] = nlevel; o[11] = nbt;
+}
+
+/* _compute_reward, chemical_reactor.py:228-270 (float32 accumulation) */
+static float cr_reward(const float *n, const float *a)
+{
+    float r = 0.0f;
+    r = r + n[4] * 100.0f;                                     /* :242 */
+    r = r - fabsf(n[0] - 320.0f) * 0.5f;                       /* :245-246 */
+    r = r - (fabsf(n[1] - 253312.5f) / 1000.0f) * 0.1f;        /* :249-250 */
+    r = r + (n[5] / 100.0f) * 10.0f;                           /* :253 */
+    if (30.0f <= n[10] && n[10] <= 80.0f) r = r + 5.0f;        /* :256-259 */
+    else r = r - fabsf(n[10] - 55.0f) * 0.2f;
+    if (n[9] > 0.5f) r = r - 50.0f;                            /* :262-263 */
+    if (n[8] > 0.5f) r = r - 200.0f;                           /* :264-265 */
+    float ap = ((0.0f + fabsf(a[0])) + fabsf(a[1])) + fabsf(a[2]); /* np.sum, n<8: sequential :268 */
+    r = r - ap * 0.1f;                                         /* :268-269 */
+    return r;
+}
+
+/* _is_done, chemical_reactor.py:272-290 */
+static int cr_done(const float *s) { return s[8] > 0.5f || s[10] < 5.0f || s[10] > 95.0f || s[11] > 50.0f; }
+
+/* constraints, chemical_reactor.py:292-305 (pre-state); 1 = satisfied */
+static void cr_checks(const float *s, const float *a, int *ok)
+{
+    (void)a;
+    ok[0] = s[0] <= 350.0f;
+    ok[1] = s[1] <= 506625.0f;
+    ok[2] = (20.0f <= s[10]) && (s[10] <= 90.0f);
+}
+
+/* ------------------------------------------------------------------------------
+ * PowerGrid-v0   (power_grid.py)
+ * ---------------------------------------------------------------------------- */
+static const double PG_BASE_LOAD[8] = {50, 60, 45, 55, 40, 65, 35, 50};   /* power_grid.py:82 (int64 array) */
+static const double PG_COST[8] = {25, 30, 28, 35, 32, 27, 40, 33};        /* power_grid.py:88 (int64 array) */
+
+/* _get_initial_state, power_grid.py:90-110.  noise = [8 V normals][8 gen normals][8 load uniforms][7 flow normals] */
+static void pg_reset(const double *n, float *s)
+{
+    s[0] = 0.0f;
+    for (int i = 0; i < 8; i++) s[1 + i] = (float)(1.0 + n[i]);                       /* :98 */
+    for (int i = 0; i < 8; i++) s[9 + i] = (float)(PG_BASE_LOAD[i] + n[8 + i]);       /* :101 */
+    for (int i = 0; i < 8; i++) s[17 + i] = (float)(PG_BASE_LOAD[i] * (1.0 + n[16 + i])); /* :104-105 */
+    for (int i = 0; i < 7; i++) s[25 + i] = (float)n[24 + i];                         /* :108 */
+}
+
+/* _dynamics, power_grid.py:112-153 */
+static void pg_dynamics(const float *s, const float *a, const double *noise, double dt, float *o)
+{
+    float f = s[0];
+    float ngen[8];
+    for (int i = 0; i < 8; i++) {                              /* :124 np.clip(gen + a, 0, 100) in float32 */
+        float g = s[9 + i] + a[i];
+        g = (g < 0.0f) ? 0.0f : g;                             /* np.clip == minimum(maximum(x, lo), hi) */
+        g = (g > 100.0f) ? 100.0f : g;
+        ngen[i] = g;
+    }
+    float tg = sum8f(ngen);                                    /* :127 */
+    float tl = sum8f(&s[17]);                                  /* :128 */
+    float imb = tg - tl;                                       /* :129 */
+    float fd = ((-1.0f * f) + imb) / 5.0f;                     /* :132 */
+    float nf = f + fd * (float)dt;                             /* :133 */
+    o[0] = nf;
+    for (int i = 0; i < 8; i++) o[1 + i] = (float)((double)s[1 + i] + noise[i]);      /* :136-137 */
+    for (int i = 0; i < 8; i++) o[9 + i] = ngen[i];
+    for (int i = 0; i < 8; i++) {                              /* :140-141 np.maximum(loads + d, 0) fp64 */
+        double l = (double)s[17 + i] + noise[8 + i];
+        l = (l < 0.0) ? 0.0 : l;                               /* NaN propagates in np.maximum; l<0 false -> keeps NaN */
+        o[17 + i] = (float)l;
+    }
+    for (int i = 0; i < 7; i++) o[25 + i] = (float)((double)s[25 + i] + noise[16 + i]); /* :144 */
+}
+
+/* _compute_reward, power_grid.py:155-177 -> Python float (fp64) */
+static double pg_reward(const float *n, const float *a)
+{
+    float fr = -100.0f * (n[0] * n[0]);                        /* :162 */
+    float dev2[8], a2[8];
+    for (int i = 0; i < 8; i++) { float d = fabsf(n[1 + i] - 1.0f); dev2[i] = d * d; } /* :165-166 */
+    float vr = -50.0f * sum8f(dev2);
+    double cg[8];
+    for (int i = 0; i < 8; i++) cg[i] = PG_COST[i] * (double)n[9 + i];                 /* :169 int64*f32 -> f64 */
+    double er = (-sum8d(cg)) / 1000.0;                         /* :170 */
+    for (int i = 0; i < 8; i++) a2[i] = a[i] * a[i];
+    float ap = -5.0f * sum8f(a2);                              /* :173 */
+    return (((double)(fr + vr)) + er) + (double)ap;            /* :175 */
+}
+
+/* _is_done, power_grid.py:179-192 (float32 compares against weak Python floats) */
+static int pg_done(const float *s)
+{
+    if (fabsf(s[0]) > 1.0f) return 1;
+    for (int i = 0; i < 8; i++) if (s[1 + i] < 0.9f || s[1 + i] > 1.1f) return 1;
+    return 0;
+}
+
+/* module-level constraints, power_grid.py:10-30 */
+static void pg_checks(const float *s, const float *a, int *ok)
+{
+    ok[0] = fabsf(s[0]) < 0.5f;
+    int v = 1, g = 1;
+    for (int i = 0; i < 8; i++) if (!(s[1 + i] >= 0.95f && s[1 + i] <= 1.05f)) v = 0;
+    for (int i = 0; i < 8; i++) {
+        float ng = s[9 + i] + a[i];                            /* float32 add; compared with 0 and f64 100 */
+        if (!(ng >= 0.0f && (double)ng <= 100.0)) g = 0;
+    }
+    ok[1] = v; ok[2] = g;
+}
+
+/* ------------------------------------------------------------------------------
+ * RobotAssembly-v0   (robot_assembly.py)
+ * ---------------------------------------------------------------------------- */
+static const double RA_L[7] = {0.3, 0.3, 0.25, 0.25, 0.15, 0.1, 0.05};   /* robot_assembly.py:85 */
+static const double RA_TGT[3] = {0.3, 0.0, 0.4};                          /* :90 */
+#define RA_PI 3.141592653589793
+
+/* _forward_kinematics, robot_assembly.py:94-111 (fp64, sequential in joint order) */
+static void ra_fk(const double *q, int flavor, double *p)
+{
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int i = 0; i < 7; i++) {
+        double sn, cs;
+        o_sincos(q[i], flavor, &sn, &cs);
+        if (i % 2 == 0) { x += RA_L[i] * cs; z += RA_L[i] * sn; }
+        else { y += RA_L[i] * sn; }
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
+
+/* _get_initial_state, robot_assembly.py:113-137.  noise = the 7 uniform joint draws themselves */
+static void ra_reset(const double *n, int flavor, float *s)
+{
+    double p[3];
+    ra_fk(n, flavor, p);
+    memset(s, 0, 24 * sizeof(float));
+    s[0] = (float)p[0]; s[1] = (float)p[1]; s[2] = (float)p[2];
+    s[3] = 0.0f; s[4] = 0.0f; s[5] = 0.0f; s[6] = 1.0f;
+    for (int i = 0; i < 7; i++) s[7 + i] = (float)n[i];
+}
+
+/* _dynamics, robot_assembly.py:139-188 */
+static void ra_dynamics(const float *s, const float *a, double dt, int flavor, float *o)
+{
+    double q[7], p[3];
+    for (int i = 0; i < 7; i++) {
+        float nq = s[7 + i] + a[i] * (float)dt;                /* :148 float32 */
+        double d = (double)nq;                                 /* :149-153 clip against fp64 limits */
+        d = (d < -RA_PI) ? -RA_PI : d;
+        d = (d > RA_PI) ? RA_PI : d;
+        q[i] = d;
+    }
+    ra_fk(q, flavor, p);                                       /* :156 */
+    double v[3];
+    for (int i = 0; i < 3; i++) v[i] = (p[i] - (double)s[i]) / dt;  /* :159-160 */
+    double dx = p[0] - RA_TGT[0], dy = p[1] - RA_TGT[1], dz = p[2] - RA_TGT[2];
+    double dist = sqrt(dx * dx + dy * dy + dz * dz);           /* :163 np.linalg.norm */
+    double F[3] = {0.0, 0.0, 0.0};
+    if (dist < 0.01) {                                         /* :164-169 */
+        double nf = pymaxd(0.0, 0.01 - dist) * 1000.0;
+        F[2] = 0.0 - nf;                                       /* -0 (int) when nf == 0 -> +0.0 stored */
+        if (nf == 0.0) F[2] = 0.0;
+    }
+    double ae = sqrt(dx * dx + dy * dy);                       /* :172 */
+    double align = pymaxd(0.0, 1.0 - ae / 0.005);              /* :173 */
+    double ins = pymaxd(0.0, RA_TGT[2] - p[2]);                /* :175 */
+    double depth = pymind(1.0, ins / 0.05);                    /* :176 */
+    double compl = align * depth;                              /* :178 */
+    memcpy(o, s, 24 * sizeof(float));
+    o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2];
+    o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f;        /* :182 */
+    for (int i = 0; i < 7; i++) o[7 + i] = (float)q[i];        /* :183 */
+    o[14] = (float)v[0]; o[15] = (float)v[1]; o[16] = (float)v[2]; o[17] = 0.0f; /* :184 */
+    o[18] = (float)F[0]; o[19] = (float)F[1]; o[20] = (float)F[2];
+    o[21] = (float)align; o[22] = (float)depth; o[23] = (float)compl;
+}
+
+/* _compute_reward, robot_assembly.py:190-222 -> Python float */
+static double ra_reward(const float *n, const float *a)
+{
+    float cr = 100.0f * n[23];                                 /* :197 */
+    double dx = (double)n[0] - RA_TGT[0], dy = (double)n[1] - RA_TGT[1], dz = (double)n[2] - RA_TGT[2];
+    double dr = -10.0 * sqrt(dx * dx + dy * dy + dz * dz);     /* :200-201 */
+    float fm = sqrtf(n[18] * n[18] + n[19] * n[19] + n[20] * n[20]);  /* :204 float32 norm */
+    float ap = 0.0f, vp = 0.0f;
+    for (int i = 0; i < 7; i++) ap = ap + a[i] * a[i];         /* :211 sequential (n<8) */
+    ap = -0.1f * ap;
+    for (int i = 0; i < 4; i++) vp = vp + n[14 + i] * n[14 + i]; /* :215 */
+    vp = -0.5f * vp;
+    double tot = (double)cr + dr;                              /* :217-220 left-to-right */
+    if (fm > 30.0f) tot = tot + (double)(-50.0f * (fm - 30.0f)); else tot = tot + 0.0;
+    tot = tot + (double)ap;
+    tot = tot + (double)vp;
+    return tot;
+}
+
+/* _is_done, robot_assembly.py:224-244 */
+static int ra_done(const float *s)
+{
+    if (s[23] > 0.95f) return 1;
+    for (int i = 0; i < 3; i++) if (fabsf(s[18 + i]) > 80.0f) return 1;
+    static const double lo[3] = {-0.6, -0.6, -0.1}, hi[3] = {0.6, 0.6, 0.9};
+    for (int i = 0; i < 3; i++) if (!((double)s[i] >= lo[i] && (double)s[i] <= hi[i])) return 1;
+    return 0;
+}
+
+/* module-level constraints, robot_assembly.py:10-32 */
+static void ra_checks(const float *s, const float *a, int *ok)
+{
+    (void)a;
+    int f = 1, c = 1, v = 1;
+    for (int i = 0; i < 3; i++) if (!(fabsf(s[18 + i]) < 50.0f)) f = 0;
+    static const double lo[3] = {-0.5, -0.5, 0.0}, hi[3] = {0.5, 0.5, 0.8};
+    for (int i = 0; i < 3; i++) if (!((double)s[i] >= lo[i] && (double)s[i] <= hi[i])) c = 0;
+    for (int i = 0; i < 7; i++) if (!(fabsf(s[7 + i]) < 2.0f)) v = 0;
+    ok[0] = f; ok[1] = c; ok[2] = v;
+}
+
+/* ------------------------------------------------------------------------------
+ * IndustrialEnv.reset / IndustrialEnv.step   (base.py:133-213)
+ * ---------------------------------------------------------------------------- */
+void oracle_reset(int env, const double *noise, int flavor, float *state)
+{
+    if (env == ORACLE_CR) cr_reset(noise, state);
+    else if (env == ORACLE_PG) pg_reset(noise, state);
+    else ra_reset(noise, flavor, state);
+}
+
+typedef struct {
+    double reward;        /* CR: exactly a float32 value; PG/RA: fp64 Python float */
+    int terminated, truncated;
+    int violation_count, critical_violations;   /* SafetyMetrics of this step (base.py:94-124) */
+    int ok[3];            /* per-constraint: 1 satisfied */
+} oracle_step_out_t;
+
+/* One IndustrialEnv.step on one env instance.  step_pre = current_step before the call. */
+void oracle_step(int env, const float *state, const float *action_raw, const double *noise,
+                 int step_pre, int max_steps, double dt, int flavor,
+                 float *next, oracle_step_out_t *out)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    float a[8];
+    for (int i = 0; i < sp->action_dim; i++) {                 /* base.py:167 np.clip(action, -1, 1) */
+        float x = action_raw[i];
+        x = (x < -1.0f) ? -1.0f : x;
+        x = (x > 1.0f) ? 1.0f : x;
+        a[i] = x;
+    }
+    int ok[3];
+    if (env == ORACLE_CR) cr_checks(state, a, ok);             /* base.py:170 */
+    else if (env == ORACLE_PG) pg_checks(state, a, ok);
+    else ra_checks(state, a, ok);
+    int viol = 0, crit = 0;
+    for (int k = 0; k < 3; k++) if (!ok[k]) { viol++; if (sp->critical[k]) crit++; }
+
+    double reward;
+    if (env == ORACLE_CR) {                                    /* base.py:173-183 */
+        cr_dynamics(state, a, noise, flavor, next);
+        float r = cr_reward(next, a);
+        for (int k = 0; k < 3; k++) if (!ok[k]) r = r + (float)sp->penalty[k];
+        if (crit > 0) r = r - 1000.0f;                         /* base.py:195-198 */
+        reward = (double)r;
+    } else {
+        double r;
+        if (env == ORACLE_PG) { pg_dynamics(state, a, noise, dt, next); r = pg_reward(next, a); }
+        else { ra_dynamics(state, a, dt, flavor, next); r = ra_reward(next, a); }
+        for (int k = 0; k < 3; k++) if (!ok[k]) r = r + sp->penalty[k];
+        if (crit > 0) r = r - 1000.0;
+        reward = r;
+    }
+    int step = step_pre + 1;                                   /* base.py:187 */
+    int term = (env == ORACLE_CR) ? cr_done(next) : (env == ORACLE_PG) ? pg_done(next) : ra_done(next);
+    int trunc = step >= max_steps;                             /* base.py:191 */
+    if (crit > 0) term = 1;                                    /* base.py:195-197 */
+    out->reward = reward;
+    out->terminated = term; out->truncated = trunc;
+    out->violation_count = viol; out->critical_violations = crit;
+    for (int k = 0; k < 3; k++) out->ok[k] = ok[k];
+}
+
+/* batched convenience for tests: row-major [n][S] states etc. */
+void oracle_step_batch(int env, int n, const float *states, const float *actions, const double *noise,
+                       const int *step_pre, int max_steps, double dt, int flavor,
+                       float *next, double *reward, int *term, int *trunc, int *viol, int *crit, int *ok)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    for (int i = 0; i < n; i++) {
+        oracle_step_out_t o;
+        oracle_step(env, states + (size_t)i * sp->state_dim, actions + (size_t)i * sp->action_dim,
+                    noise ? noise + (size_t)i * sp->k_step : NULL, step_pre[i], max_steps, dt, flavor,
+                    next + (size_t)i * sp->state_dim, &o);
+        reward[i] = o.reward; term[i] = o.terminated; trunc[i] = o.truncated;
+        viol[i] = o.violation_count; crit[i] = o.critical_violations;
+        for (int k = 0; k < 3; k++) ok[i * 3 + k] = o.ok[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------
+ * Synthetic input generator "nig-philox-v1" (DESIGN.md).  NOT part of the reference
+ * (which draws from NumPy's global MT19937): it is the workload generator that
+ * bench.py and the full-size parity tests use on both the CPU and the GPU side.
+ * Independent restatement of the spec; the product has its own implementation.
+ * ---------------------------------------------------------------------------- */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define STREAM_STEP 0u
+#define STREAM_RESET 0x40000000u
+#define STREAM_ACTION 0x80000000u
+
+/* two standard normals from two u32 (Box-Muller on 24-bit uniforms, detmath) */
+static void bm_pair(uint32_t x0, uint32_t x1, float *z0, float *z1)
+{
+    float u1 = (float)((x0 >> 8) + 1u) * (1.0f / 16777216.0f);     /* (0, 1] */
+    float r = sqrtf(-2.0f * det_logf(u1));
+    float s, c;
+    det_sincos2pi_u24(x1 >> 8, &s, &c);
+    *z0 = r * c; *z1 = r * s;
+}
+
+static double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }  /* [0,1) */
+
+/* n standard normals for (env_index, t) on a stream */
+static void gen_normals(uint64_t seed, uint64_t env_index, uint32_t t, uint32_t stream, int n, float *z)
+{
+    uint32_t x[4];
+    for (int j = 0; 4 * j < n; j++) {
+        philox4x32_10((uint32_t)env_index, (uint32_t)(env_index >> 32), t, stream + (uint32_t)j,
+                      (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        float a, b, c, d;
+        bm_pair(x[0], x[1], &a, &b);
+        bm_pair(x[2], x[3], &c, &d);
+        float q[4] = {a, b, c, d};
+        for (int i = 0; i < 4 && 4 * j + i < n; i++) z[4 * j + i] = q[i];
+    }
+}
+
+static void gen_uniforms(uint64_t seed, uint64_t env_index, uint32_t t, uint32_t stream, int n, double *u)
+{
+    uint32_t x[4];
+    for (int j = 0; 4 * j < n; j++) {
+        philox4x32_10((uint32_t)env_index, (uint32_t)(env_index >> 32), t, stream + (uint32_t)j,
+                      (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        for (int i = 0; i < 4 && 4 * j + i < n; i++) u[4 * j + i] = u01(x[i]);
+    }
+}
+
+/* step noise in the reference's draw order and scaling (loc + scale * z, fp64) */
+void oracle_gen_step_noise(int env, uint64_t seed, uint64_t env_index, uint32_t t, double *noise)
+{
+    float z[24];
+    if (env == ORACLE_CR) {                                    /* chemical_reactor.py:149,159 */
+        gen_normals(seed, env_index, t, STREAM_STEP, 2, z);
+        noise[0] = 0.0 + 0.1 * (double)z[0];
+        noise[1] = 0.0 + 500.0 * (double)z[1];
+    } else if (env == ORACLE_PG) {                             /* power_grid.py:136,140,144 */
+        gen_normals(seed, env_index, t, STREAM_STEP, 23, z);
+        for (int i = 0; i < 8; i++) noise[i] = 0.0 + 0.005 * (double)z[i];
+        for (int i = 0; i < 8; i++) noise[8 + i] = 0.0 + 1.0 * (double)z[8 + i];
+        for (int i = 0; i < 7; i++) noise[16 + i] = 0.0 + 2.0 * (double)z[16 + i];
+    }
+}
+
+void oracle_gen_reset_noise(int env, uint64_t seed, uint64_t env_index, uint32_t t, double *noise)
+{
+    float z[24];
+    double u[8];
+    if (env == ORACLE_CR) {                                    /* chemical_reactor.py:93-103 */
+        static const double sc[8] = {2, 10000, 5, 3, 0.1, 2, 1, 5};
+        gen_normals(seed, env_index, t, STREAM_RESET, 8, z);
+        for (int i = 0; i < 8; i++) noise[i] = 0.0 + sc[i] * (double)z[i];
+    } else if (env == ORACLE_PG) {                             /* power_grid.py:98-108 */
+        gen_normals(seed, env_index, t, STREAM_RESET, 23, z);
+        gen_uniforms(seed, env_index, t, STREAM_RESET + 16u, 8, u);
+        for (int i = 0; i < 8; i++) noise[i] = 0.0 + 0.01 * (double)z[i];
+        for (int i = 0; i < 8; i++) noise[8 + i] = 0.0 + 2.0 * (double)z[8 + i];
+        for (int i = 0; i < 8; i++) noise[16 + i] = -0.2 + (0.2 - -0.2) * u[i];
+        for (int i = 0; i < 7; i++) noise[24 + i] = 0.0 + 10.0 * (double)z[16 + i];
+    } else {                                                   /* robot_assembly.py:118-122 */
+        gen_uniforms(seed, env_index, t, STREAM_RESET, 7, u);
+        const double lo = -RA_PI * 0.5, hi = RA_PI * 0.5;
+        for (int i = 0; i < 7; i++) noise[i] = lo + (hi - lo) * u[i];
+    }
+}
+
+/* uniform float32 actions in [-1, 1): 2*u - 1 with u a 24-bit uniform (exact in float32) */
+void oracle_gen_actions(int env, uint64_t seed, uint64_t env_index, uint32_t t, float *a)
+{
+    double u[8];
+    gen_uniforms(seed, env_index, t, STREAM_ACTION, SPECS[env].action_dim, u);
+    for (int i = 0; i < SPECS[env].action_dim; i++) a[i] = (float)(2.0 * u[i] - 1.0);
+}
+
+/* ------------------------------------------------------------------------------
+ * Free-running rollout driver (auto-reset), used as (1) the exact cross-check for the
+ * device "fast mode" and (2) bench.py's cpu_baseline.  Mirrors the loop shape of the
+ * reference's benchmark_environment_steps (performance_benchmark.py:106-133):
+ * sample action -> step -> reset on done.  Env i uses global index env0 + i.
+ *
+ * Per-env outputs after T steps (arrays of n): final state [n][S] row-major,
+ * int64 sums: steps, episodes finished, violation_count, critical_violations,
+ * terminated count, truncated count; double sum of rewards.
+ * ---------------------------------------------------------------------------- */
+typedef struct {
+    int64_t steps, episodes, violations, critical, terminated, truncated;
+    double reward_sum;
+} oracle_tally_t;
+
+void oracle_rollout(int env, int64_t n, uint64_t env0, uint64_t seed, uint32_t t0, int T,
+                    int max_steps, double dt, int flavor, int nthreads,
+                    float *state_io /* [n][S] in: ignored if init!=0 */, int32_t *step_io /* [n] */,
+                    int init, oracle_tally_t *tally /* [n] or NULL */, oracle_tally_t *total)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    const int S = sp->state_dim;
+    oracle_tally_t tot; memset(&tot, 0, sizeof tot);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    {
+        oracle_tally_t loc; memset(&loc, 0, sizeof loc);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t i = 0; i < n; i++) {
+            float s[32], nx[32], a[8];
+            double nz[32];
+            uint64_t gi = env0 + (uint64_t)i;
+            int step;
+            oracle_tally_t me; memset(&me, 0, sizeof me);
+            if (init) {
+                oracle_gen_reset_noise(env, seed, gi, t0, nz);
+                oracle_reset(env, nz, flavor, s);
+                step = 0;
+            } else {
+                memcpy(s, state_io + (size_t)i * S, S * sizeof(float));
+                step = step_io[i];
+            }
+            for (int k = 0; k < T; k++) {
+                uint32_t t = t0 + 1u + (uint32_t)k;
+                oracle_step_out_t o;
+                oracle_gen_actions(env, seed, gi, t, a);
+                oracle_gen_step_noise(env, seed, gi, t, nz);
+                oracle_step(env, s, a, nz, step, max_steps, dt, flavor, nx, &o);
+                me.steps++; me.violations += o.violation_count; me.critical += o.critical_violations;
+                me.reward_sum += o.reward;
+                me.terminated += o.terminated; me.truncated += (o.truncated && !o.terminated);
+                if (o.terminated || o.truncated) {
+                    me.episodes++;
+                    oracle_gen_reset_noise(env, seed, gi, t, nz);
+                    oracle_reset(env, nz, flavor, s);
+                    step = 0;
+                } else {
+                    memcpy(s, nx, S * sizeof(float));
+                    step++;
+                }
+            }
+            memcpy(state_io + (size_t)i * S, s, S * sizeof(float));
+            step_io[i] = step;
+            if (tally) tally[i] = me;
+            loc.steps += me.steps; loc.episodes += me.episodes; loc.violations += me.violations;
+            loc.critical += me.critical; loc.terminated += me.terminated; loc.truncated += me.truncated;
+            loc.reward_sum += me.reward_sum;
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            tot.steps += loc.steps; tot.episodes += loc.episodes; tot.violations += loc.violations;
+            tot.critical += loc.critical; tot.terminated += loc.terminated; tot.truncated += loc.truncated;
+            tot.reward_sum += loc.reward_sum;
+        }
+    }
+    if (total) *total = tot;
+}
+
+/* exposed for unit tests of the math layer */
+float oracle_det_expf(float x) { return det_expf(x); }
+float oracle_det_logf(float x) { return det_logf(x); }
+void oracle_det_sincos2pi_u24(uint32_t k, float *s, float *c) { det_sincos2pi_u24(k, s, c); }
+void oracle_det_sincos(double x, double *s, double *c) { det_sincos(x, s, c); }
+void oracle_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
+{
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+void oracle_gen_normals(uint64_t seed, uint64_t env_index, uint32_t t, uint32_t stream, int n, float *z)
+{
+    gen_normals(seed, env_index, t, stream, n, z);
+}
