@@ -1,0 +1,211 @@
+/*
+ * nig.h -- C ABI of libnig.so: the MI355X-native batched simulator for the
+ * IndustrialEnv.step() hot path of neoRL-industrial-gym.
+ *
+ * The reference has NO native/FFI layer: its boundary is the
+ * Python class surface IndustrialEnv.reset/step (environments/base.py:133-213),
+ * utils.make (utils.py:12-39) and utils.evaluate_with_safety (utils.py:42-154).
+ * Each entry point below names the reference interface it stands in for.  The
+ * Python mirror of that surface (neorl-industrial-gym_amd/) is a thin ctypes shim
+ * over exactly these symbols; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns an int status, 0 = NIG_OK; nig_last_error() explains
+ *     the last failure on the calling thread;
+ *   - all data pointers are DEVICE pointers unless a parameter says "host";
+ *   - batch arrays are structure-of-arrays: row k of a [R][B] array starts at
+ *     element k*ld, where ld = nig_layout.ld (B rounded up to 64) for library-owned
+ *     arrays and ld = the ld_* argument for caller-owned arrays;
+ *   - every launch goes to the caller-supplied hipStream_t (passed as void*), no
+ *     hidden synchronisation; a handle is not thread-safe, distinct handles are;
+ *   - there is no CPU fallback: without a HIP device nig_create fails.
+ */
+#ifndef NIG_H
+#define NIG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIG_OK 0
+#define NIG_ERR_INVALID 1      /* bad argument                                   */
+#define NIG_ERR_HIP 2          /* a HIP runtime call failed                      */
+#define NIG_ERR_NODEVICE 3     /* no usable HIP device                           */
+#define NIG_ERR_UNSUPPORTED 4
+
+/* environment ids: the registry of utils.py:26-32 (working environments) */
+#define NIG_ENV_CHEMICAL_REACTOR 0   /* 'ChemicalReactor-v0'  environments/chemical_reactor.py */
+#define NIG_ENV_POWER_GRID 1         /* 'PowerGrid-v0'        environments/power_grid.py       */
+#define NIG_ENV_ROBOT_ASSEMBLY 2     /* 'RobotAssembly-v0'    environments/robot_assembly.py   */
+#define NIG_NUM_ENVS 3
+
+/* nig_create flags */
+#define NIG_F_AUTORESET 0x1u   /* finished lanes re-sample their initial state inside the step kernel   */
+#define NIG_F_TALLY 0x2u       /* keep per-lane episode tallies (what evaluate_with_safety aggregates)   */
+
+/* per-lane flag word written by nig_step (one uint32 per env instance per step) */
+#define NIG_FLAG_TERMINATED 0x1u        /* base.py:190,195-197                               */
+#define NIG_FLAG_TRUNCATED 0x2u         /* base.py:191                                       */
+#define NIG_FLAG_VIOL0 0x4u             /* constraint k violated on the pre-state: bit 2+k   */
+#define NIG_FLAG_VIOL_SHIFT 2
+#define NIG_FLAG_NVIOL_SHIFT 5          /* bits 5-6: SafetyMetrics.violation_count (0..3)    */
+#define NIG_FLAG_NCRIT_SHIFT 7          /* bits 7-8: SafetyMetrics.critical_violations       */
+#define NIG_FLAG_SHUTDOWN 0x200u        /* info['critical_shutdown'], base.py:210            */
+#define NIG_FLAG_DID_RESET 0x400u       /* lane auto-reset in this call (state = new episode)*/
+#define NIG_FLAG_INACTIVE 0x800u        /* lane was already done (no auto-reset): untouched  */
+#define NIG_FLAG_STEP_SHIFT 16          /* bits 16-31: current_step after this call          */
+
+/* per-lane counter word kept by the library */
+#define NIG_CTR_STEP_MASK 0x7fffu       /* current_step (base.py:187)                        */
+#define NIG_CTR_DONE 0x8000u            /* self.done (base.py:192,197)                       */
+#define NIG_CTR_VIOL_SHIFT 16           /* violation_count of the running episode (base.py:182) */
+#define NIG_MAX_EPISODE_STEPS 21845     /* keeps 3*steps inside 16 bits                      */
+
+/* rows of the tally array (NIG_F_TALLY), all stored as double, one column per lane */
+enum {
+    NIG_T_EPISODES = 0,   /* finished episodes                                   utils.py:120 */
+    NIG_T_RET_SUM,        /* sum of episode returns                              utils.py:130 */
+    NIG_T_RET_SQ,         /* sum of squared episode returns                      utils.py:131 */
+    NIG_T_RET_MIN,        /*                                                     utils.py:132 */
+    NIG_T_RET_MAX,        /*                                                     utils.py:133 */
+    NIG_T_LEN_SUM,        /* sum of episode lengths (= steps in finished eps)    utils.py:136 */
+    NIG_T_LEN_SQ,         /*                                                     utils.py:137 */
+    NIG_T_VIOL,           /* sum of SafetyMetrics.violation_count                utils.py:140 */
+    NIG_T_CRIT,           /* sum of SafetyMetrics.critical_violations            utils.py:142 */
+    NIG_T_SHUTDOWN,       /* steps with info['critical_shutdown']                utils.py:143 */
+    NIG_T_SUCCESS,        /* episodes with return > 0                            utils.py:150 */
+    NIG_T_ROWS
+};
+
+/* static description of an environment: base.py:22-72 plus each env's ctor */
+typedef struct nig_env_spec {
+    int32_t state_dim;          /* base.py:41  */
+    int32_t action_dim;         /* base.py:42  */
+    int32_t n_constraints;      /* len(self.safety_constraints)              */
+    int32_t max_episode_steps;  /* default: CR 500 (chemical_reactor.py:66), PG/RA 1000 (base.py:27) */
+    int32_t k_step;             /* RNG values drawn per step, reference call order  */
+    int32_t k_reset;            /* RNG values drawn per reset                       */
+    double dt;                  /* base.py:28 */
+    double penalty[3];          /* SafetyConstraint.penalty  */
+    int32_t critical[3];        /* SafetyConstraint.critical */
+    int32_t reward_is_f32;      /* 1: reward accumulates in float32 (CR, NumPy>=2), 0: fp64 */
+} nig_env_spec;
+
+/* byte offsets of the library-owned arrays inside the handle's workspace */
+typedef struct nig_layout {
+    int64_t batch;          /* B                                              */
+    int64_t ld;             /* row pitch in elements of every [R][B] array    */
+    int64_t bytes;          /* total workspace size                           */
+    int64_t off_state;      /* float  [S][ld]  current state == observation   */
+    int64_t off_ctr;        /* uint32 [ld]     counter word (NIG_CTR_*)       */
+    int64_t off_life_viol;  /* int64  [ld]     total_violations of FINISHED episodes (base.py:57,183) */
+    int64_t off_ep_return;  /* double [ld]     return of the running episode (NIG_F_TALLY only, else -1) */
+    int64_t off_tally;      /* double [NIG_T_ROWS][ld]  (NIG_F_TALLY only, else -1) */
+} nig_layout;
+
+typedef struct nig_handle nig_handle;
+
+const char *nig_version(void);
+const char *nig_last_error(void);
+
+/* utils.make registry lookup (utils.py:26-35): name -> id, or -1 */
+int nig_env_id(const char *name);
+const char *nig_env_name(int env);
+int nig_env_spec_get(int env, nig_env_spec *out);
+
+/* Workspace size/layout for a batch; `flags` as for nig_create. */
+int nig_layout_query(int env, int64_t batch, uint32_t flags, nig_layout *out);
+
+/*
+ * Construct a batch of `batch` independent env instances of one type on `device`
+ * (stands in for B calls of utils.make / IndustrialEnv.__init__, base.py:22-72).
+ *   env_index0         global index of lane 0 (keys the counter-based RNG so results do
+ *                      not depend on how a job is sharded over GPUs)
+ *   max_episode_steps  0 = the env's default; CR ignores overrides upstream
+ *                      (chemical_reactor.py:62-69 hard-codes 500 / 0.1), here it is honoured
+ *   dt                 0 = default
+ *   workspace          device memory of nig_layout.bytes (256-byte aligned) owned by the
+ *                      caller, or NULL to let the library hipMalloc it
+ * States are undefined until nig_reset.
+ */
+int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_index0,
+               int32_t max_episode_steps, double dt, uint32_t flags, void *workspace,
+               nig_handle **out);
+int nig_destroy(nig_handle *h);
+int nig_get_layout(const nig_handle *h, nig_layout *out);
+void *nig_workspace(const nig_handle *h);
+
+/* RNG launch counter t ("nig-philox-v1"): nig_reset draws with the current
+ * t, nig_step increments t first.  Exposed so a caller can checkpoint / replay. */
+int nig_get_counter(const nig_handle *h, uint32_t *t);
+int nig_set_counter(nig_handle *h, uint32_t t);
+
+/* env.remove_safety_constraint(name) for a built-in constraint (base.py:224-228): bit k of
+ * `mask` keeps constraint k enabled (default 0x7).  A disabled constraint is neither
+ * counted nor penalised.  Constraints ADDED by the user (base.py:220-222) are arbitrary
+ * Python callables and stay on the host side of the binding. */
+int nig_set_constraint_mask(nig_handle *h, uint32_t mask);
+
+/*
+ * IndustrialEnv.reset (base.py:133-155) for the lanes selected by `mask`
+ * (uint8 [B], NULL = all): current_step = 0, done = False, violation_count = 0,
+ * state = _get_initial_state().
+ *   init_noise   double [k_reset][ld_noise]: the values the reference's RNG calls
+ *                would have returned, in call order ("parity mode"); NULL = draw
+ *                them on device from the counter-based generator ("fast mode").
+ */
+int nig_reset(nig_handle *h, const uint8_t *mask, const double *init_noise, int64_t ld_noise,
+              void *stream);
+
+/*
+ * IndustrialEnv.step (base.py:157-213) for every lane, one kernel launch.
+ *   actions      float [A][ld_act]   raw actions (clipped to [-1,1] inside, base.py:167)
+ *   step_noise   double [k_step][ld_noise] or NULL (fast mode)
+ *   reset_noise  double [k_reset][ld_noise] or NULL: initial-state draws for lanes that
+ *                auto-reset in this call (NIG_F_AUTORESET)
+ *   reward_out   float [B]   reward (rounded to float32 for PG/RA)        may be NULL
+ *   reward64_out double [B]  the reference's fp64 Python-float reward      may be NULL
+ *   flags_out    uint32 [B]  NIG_FLAG_* word                               may be NULL
+ *   final_obs    float [S][ld_obs] terminal observation of lanes that finished in this
+ *                call (other lanes untouched)                              may be NULL
+ * The new state/observation is the library-owned state array (nig_layout.off_state);
+ * with NIG_F_AUTORESET a finished lane already holds the first observation of its next
+ * episode.  Without it a finished lane is frozen until nig_reset (the reference raises
+ * RuntimeError, base.py:159-160; here its flag word reads NIG_FLAG_INACTIVE).
+ */
+int nig_step(nig_handle *h, const float *actions, int64_t ld_act,
+             const double *step_noise, const double *reset_noise, int64_t ld_noise,
+             float *reward_out, double *reward64_out, uint32_t *flags_out,
+             float *final_obs, int64_t ld_obs, void *stream);
+
+/* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
+ * "action" for launch counter `t` (bench / parity workload generator). */
+int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);
+
+/* Teacher forcing / checkpointing: copy state, counter words in or out (device pointers,
+ * float [S][ld], uint32 [B]); either pointer may be NULL. */
+int nig_set_state(nig_handle *h, const float *state, int64_t ld, const uint32_t *ctr, void *stream);
+int nig_get_state(nig_handle *h, float *state, int64_t ld, uint32_t *ctr, void *stream);
+
+/*
+ * env.get_safety_metrics() for every lane (named by the reference README; defined as
+ * the SafetyMetrics of the last step, base.py:94-124): int32 [5][ld_out] rows =
+ * constraints_satisfied, total_constraints, violation_count, critical_violations,
+ * and safety_score*total (== satisfied), decoded from a flag array of the last step.
+ */
+int nig_get_safety_metrics(nig_handle *h, const uint32_t *flags, int32_t *out, int64_t ld_out,
+                           void *stream);
+
+/*
+ * Reduce the per-lane tallies (NIG_F_TALLY) to one partial vector double[NIG_T_ROWS]
+ * on the device (sum rows, min/max rows).  `partial_out` is a DEVICE pointer.  The
+ * cross-GPU combine is an all-gather of these vectors (see parallel.py).
+ */
+int nig_reduce_tally(nig_handle *h, double *partial_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIG_H */

@@ -1,0 +1,27 @@
+"""neorl-industrial-gym on MI355X: the IndustrialEnv.step() hot path as HIP kernels.
+
+Usage mirrors the reference package (`import neorl_industrial as ni`):
+
+    import neorl_industrial_gym_amd as ni
+    env = ni.make('ChemicalReactor-v0')                     # single env, reference surface
+    benv = ni.make_batched('ChemicalReactor-v0', 65536)     # 65536 lanes, one kernel per step
+    metrics = ni.evaluate_with_safety(agent, env, n_episodes=100)
+
+Everything numerical runs in libnig.so (csrc/, C ABI in include/nig.h).  There is no CPU
+fallback: importing the package without the built extension raises ImportError.
+"""
+from . import _lib
+from .core import DatasetQuality, SafetyConstraint, SafetyMetrics
+
+_lib.lib()   # fail loudly here if libnig.so is missing
+
+from .batched import BatchedIndustrialEnv, StepInfo  # noqa: E402
+from .envs import ChemicalReactorEnv, IndustrialEnv, PowerGridEnv, RobotAssemblyEnv  # noqa: E402
+from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
+
+__version__ = "0.1.0"
+__all__ = [
+    "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
+    "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "BatchedIndustrialEnv", "StepInfo",
+    "make", "make_batched", "evaluate_with_safety",
+]

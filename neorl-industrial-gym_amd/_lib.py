@@ -1,0 +1,103 @@
+"""ctypes binding of include/nig.h (libnig.so).  No torch types cross this boundary:
+device pointers are plain integers (tensor.data_ptr()), streams are hipStream_t handles.
+
+The extension is mandatory: importing this module without a built libnig.so raises.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+NIG_OK = 0
+F_AUTORESET, F_TALLY = 0x1, 0x2
+FLAG_TERMINATED, FLAG_TRUNCATED = 0x1, 0x2
+FLAG_VIOL_SHIFT, FLAG_NVIOL_SHIFT, FLAG_NCRIT_SHIFT = 2, 5, 7
+FLAG_SHUTDOWN, FLAG_DID_RESET, FLAG_INACTIVE, FLAG_STEP_SHIFT = 0x200, 0x400, 0x800, 16
+CTR_STEP_MASK, CTR_DONE, CTR_VIOL_SHIFT = 0x7FFF, 0x8000, 16
+MAX_EPISODE_STEPS = 21845
+(T_EPISODES, T_RET_SUM, T_RET_SQ, T_RET_MIN, T_RET_MAX, T_LEN_SUM, T_LEN_SQ, T_VIOL, T_CRIT,
+ T_SHUTDOWN, T_SUCCESS, T_ROWS) = range(12)
+
+SYMBOLS = [
+    "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
+    "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
+    "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
+    "nig_get_safety_metrics", "nig_reduce_tally",
+]
+
+
+class EnvSpec(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("action_dim", C.c_int32), ("n_constraints", C.c_int32),
+                ("max_episode_steps", C.c_int32), ("k_step", C.c_int32), ("k_reset", C.c_int32),
+                ("dt", C.c_double), ("penalty", C.c_double * 3), ("critical", C.c_int32 * 3),
+                ("reward_is_f32", C.c_int32)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("ld", C.c_int64), ("bytes", C.c_int64), ("off_state", C.c_int64),
+                ("off_ctr", C.c_int64), ("off_life_viol", C.c_int64), ("off_ep_return", C.c_int64),
+                ("off_tally", C.c_int64)]
+
+
+class NigError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libnig.so (building it first if the sources are newer and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.stale() and _build.find_hipcc():
+        _build.build()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i64, u32, u64, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_int32
+    L.nig_version.restype = C.c_char_p
+    L.nig_last_error.restype = C.c_char_p
+    L.nig_env_id.argtypes = [C.c_char_p]
+    L.nig_env_name.restype = C.c_char_p
+    L.nig_env_name.argtypes = [C.c_int]
+    L.nig_env_spec_get.argtypes = [C.c_int, C.POINTER(EnvSpec)]
+    L.nig_layout_query.argtypes = [C.c_int, i64, u32, C.POINTER(Layout)]
+    L.nig_create.argtypes = [C.c_int, i64, C.c_int, u64, u64, i32, C.c_double, u32, vp, C.POINTER(vp)]
+    L.nig_destroy.argtypes = [vp]
+    L.nig_get_layout.argtypes = [vp, C.POINTER(Layout)]
+    L.nig_workspace.restype = vp
+    L.nig_workspace.argtypes = [vp]
+    L.nig_get_counter.argtypes = [vp, C.POINTER(u32)]
+    L.nig_set_counter.argtypes = [vp, u32]
+    L.nig_set_constraint_mask.argtypes = [vp, u32]
+    L.nig_reset.argtypes = [vp, vp, vp, i64, vp]
+    L.nig_step.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp]
+    L.nig_fill_actions.argtypes = [vp, u32, vp, i64, vp]
+    L.nig_set_state.argtypes = [vp, vp, i64, vp, vp]
+    L.nig_get_state.argtypes = [vp, vp, i64, vp, vp]
+    L.nig_get_safety_metrics.argtypes = [vp, vp, vp, i64, vp]
+    L.nig_reduce_tally.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != NIG_OK:
+        raise NigError(f"libnig error {status}: {lib().nig_last_error().decode()}")
+
+
+def env_spec(env_id: int) -> EnvSpec:
+    s = EnvSpec()
+    check(lib().nig_env_spec_get(env_id, C.byref(s)))
+    return s
+
+
+def layout_query(env_id: int, batch: int, flags: int) -> Layout:
+    lay = Layout()
+    check(lib().nig_layout_query(env_id, batch, flags, C.byref(lay)))
+    return lay

@@ -1,0 +1,319 @@
+"""BatchedIndustrialEnv: B independent env instances of one type stepped by ONE HIP kernel.
+
+This is the batched form of IndustrialEnv (reference environments/base.py:19-228): the
+same reset/step semantics per lane, with every per-step Python object of the reference
+(`SafetyMetrics`, the `info` dict) replaced by a packed flag word per lane that can be
+decoded lazily.  torch is used only for device memory and the stream handle; all compute
+happens in libnig.so through the C ABI (include/nig.h).
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .core import SafetyMetrics, make_box
+
+ENV_IDS = {"ChemicalReactor-v0": 0, "PowerGrid-v0": 1, "RobotAssembly-v0": 2}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class StepInfo:
+    """Lazy view of the per-lane flag words of one step (the batched `info`).
+
+    Fields are torch tensors on the env's device, decoded on first use:
+      terminated, truncated, done, violation_count, critical_violations, critical_shutdown,
+      constraint_violated [3,B], did_reset, inactive, step.
+    """
+
+    def __init__(self, flags: torch.Tensor):
+        self.flags = flags
+
+    @property
+    def terminated(self):
+        return (self.flags & _lib.FLAG_TERMINATED) != 0
+
+    @property
+    def truncated(self):
+        return (self.flags & _lib.FLAG_TRUNCATED) != 0
+
+    @property
+    def done(self):
+        return (self.flags & (_lib.FLAG_TERMINATED | _lib.FLAG_TRUNCATED)) != 0
+
+    @property
+    def violation_count(self):
+        return (self.flags >> _lib.FLAG_NVIOL_SHIFT) & 3
+
+    @property
+    def critical_violations(self):
+        return (self.flags >> _lib.FLAG_NCRIT_SHIFT) & 3
+
+    @property
+    def critical_shutdown(self):
+        return (self.flags & _lib.FLAG_SHUTDOWN) != 0
+
+    @property
+    def constraint_violated(self):
+        return torch.stack([((self.flags >> (_lib.FLAG_VIOL_SHIFT + k)) & 1) != 0 for k in range(3)])
+
+    @property
+    def did_reset(self):
+        return (self.flags & _lib.FLAG_DID_RESET) != 0
+
+    @property
+    def inactive(self):
+        return (self.flags & _lib.FLAG_INACTIVE) != 0
+
+    @property
+    def step(self):
+        return (self.flags >> _lib.FLAG_STEP_SHIFT) & 0xFFFF
+
+    def safety_metrics(self, lane: int) -> SafetyMetrics:
+        """The reference's per-step SafetyMetrics object for one lane (base.py:118-124)."""
+        f = int(self.flags[lane].item())
+        nv = (f >> _lib.FLAG_NVIOL_SHIFT) & 3
+        nc = (f >> _lib.FLAG_NCRIT_SHIFT) & 3
+        return SafetyMetrics(constraints_satisfied=3 - nv, total_constraints=3, violation_count=nv,
+                             critical_violations=nc, safety_score=(3 - nv) / 3)
+
+
+class BatchedIndustrialEnv:
+    """B lanes of `env_id` on one GPU.
+
+    Args mirror IndustrialEnv.__init__ (base.py:22-29) plus the batch controls:
+      batch            number of env instances (lanes)
+      device           torch device ("cuda:0")
+      seed             key of the counter-based generator used in fast mode
+      env_index0       global index of lane 0 (sharding-invariant RNG streams)
+      autoreset        finished lanes start their next episode inside the step kernel
+      tally            keep per-lane episode tallies for evaluate_with_safety
+    Layouts: `state` / `obs` is the library-owned SoA array viewed as [B, S] with strides
+    (1, ld) -- a zero-copy view a policy network can consume directly; actions are
+    accepted as [A, B] (native SoA, no copy) or [B, A] (transposed on the way in).
+    """
+
+    def __init__(self, env_id: str, batch: int, device="cuda:0", seed: int = 0x5EED, env_index0: int = 0,
+                 max_episode_steps: Optional[int] = None, dt: Optional[float] = None, autoreset: bool = True,
+                 tally: bool = False):
+        if env_id not in ENV_IDS:
+            available = ", ".join(ENV_IDS.keys())
+            raise ValueError(f"Unknown environment '{env_id}'. Available: {available}")
+        self.env_id = env_id
+        self._eid = ENV_IDS[env_id]
+        self._L = _lib.lib()
+        self.spec = _lib.env_spec(self._eid)
+        self.state_dim, self.action_dim = int(self.spec.state_dim), int(self.spec.action_dim)
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedIndustrialEnv needs a HIP device (torch device type 'cuda'); "
+                               "there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to torch; BatchedIndustrialEnv has no CPU fallback")
+        self.max_episode_steps = int(max_episode_steps) if max_episode_steps else int(self.spec.max_episode_steps)
+        self.dt = float(dt) if dt else float(self.spec.dt)
+        self.autoreset, self.tally_enabled = bool(autoreset), bool(tally)
+        self._flags = (_lib.F_AUTORESET if autoreset else 0) | (_lib.F_TALLY if tally else 0)
+        lay = _lib.layout_query(self._eid, self.batch, self._flags)
+        self.ld = int(lay.ld)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(dev_index):
+            self._ws = torch.empty(int(lay.bytes), dtype=torch.uint8, device=self.device)
+            assert self._ws.data_ptr() % 256 == 0
+            h = C.c_void_p()
+            _lib.check(self._L.nig_create(self._eid, self.batch, dev_index, C.c_uint64(seed), C.c_uint64(env_index0),
+                                          self.max_episode_steps if max_episode_steps else 0,
+                                          C.c_double(self.dt if dt else 0.0), self._flags,
+                                          C.c_void_p(self._ws.data_ptr()), C.byref(h)))
+        self._h = h
+        self._dev_index = dev_index
+        B, ld, S = self.batch, self.ld, self.state_dim
+
+        def view(off, nbytes, dtype):
+            return self._ws[off:off + nbytes].view(dtype)
+
+        self.state_soa = view(lay.off_state, S * ld * 4, torch.float32).view(S, ld)[:, :B]   # [S, B]
+        self.obs = self.state_soa.t()                                                       # [B, S] strided view
+        self.ctr = view(lay.off_ctr, ld * 4, torch.int32)[:B]
+        self.life_viol = view(lay.off_life_viol, ld * 8, torch.int64)[:B]
+        if tally:
+            self.ep_return = view(lay.off_ep_return, ld * 8, torch.float64)[:B]
+            self.tally = view(lay.off_tally, _lib.T_ROWS * ld * 8, torch.float64).view(_lib.T_ROWS, ld)[:, :B]
+        else:
+            self.ep_return = self.tally = None
+        self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.reward64 = torch.zeros(B, dtype=torch.float64, device=self.device)
+        self.flags = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._act_soa = torch.zeros(self.action_dim, ld, dtype=torch.float32, device=self.device)
+        self.observation_space = make_box(-np.inf, np.inf, (self.state_dim,), np.float32)
+        self.action_space = make_box(-1.0, 1.0, (self.action_dim,), np.float32)
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nig_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _noise(self, x, rows):
+        """numpy/torch [rows, B] (or [B, rows]) fp64 -> contiguous device [rows, B]."""
+        if x is None:
+            return None
+        t = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        if t.shape == (self.batch, rows) and rows != self.batch:
+            t = t.t()
+        if t.shape != (rows, self.batch):
+            raise ValueError(f"noise must have shape ({rows}, {self.batch}), got {tuple(t.shape)}")
+        return t.contiguous()
+
+    # ------------------------------------------------------------------
+    @property
+    def counter(self) -> int:
+        t = C.c_uint32()
+        _lib.check(self._L.nig_get_counter(self._h, C.byref(t)))
+        return int(t.value)
+
+    @counter.setter
+    def counter(self, t: int):
+        _lib.check(self._L.nig_set_counter(self._h, C.c_uint32(t)))
+
+    def set_constraint_mask(self, mask: int):
+        _lib.check(self._L.nig_set_constraint_mask(self._h, C.c_uint32(mask)))
+
+    @property
+    def current_step(self):
+        return self.ctr & _lib.CTR_STEP_MASK
+
+    @property
+    def done(self):
+        return (self.ctr & _lib.CTR_DONE) != 0
+
+    @property
+    def violation_count(self):
+        return (self.ctr >> _lib.CTR_VIOL_SHIFT) & 0xFFFF
+
+    @property
+    def total_violations(self):
+        """base.py:57,183: lifetime count = finished episodes + the running one."""
+        running = torch.where(self.done, torch.zeros_like(self.ctr), self.violation_count)
+        return self.life_viol + running.to(torch.int64)
+
+    # ------------------------------------------------------------------
+    def reset(self, mask=None, init_noise=None):
+        """IndustrialEnv.reset (base.py:133-155) for all lanes or those where mask != 0.
+        init_noise: optional [k_reset, B] fp64 draws (parity mode).  Returns the obs view."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        nz = self._noise(init_noise, int(self.spec.k_reset))
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_reset(self._h, _ptr(m), _ptr(nz), self.batch, self._stream()))
+        return self.obs
+
+    def step(self, actions, step_noise=None, reset_noise=None, final_obs: Optional[torch.Tensor] = None,
+             layout: Optional[str] = None):
+        """IndustrialEnv.step (base.py:157-213) for every lane: one kernel launch.
+
+        actions: [A, B] (SoA, zero-copy) or [B, A] float32 tensor/array on any device;
+        `layout` ("soa"/"aos") disambiguates when A == B (default then: [B, A]).
+        Returns (obs [B,S] view, reward f32 [B], terminated [B], truncated [B], StepInfo).
+        """
+        A, B = self.action_dim, self.batch
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.float32:
+            a = a.to(torch.float32)      # the reference semantics pinned here are float32 actions
+        if layout in ("soa", "aos"):
+            soa = layout == "soa"
+        else:
+            soa = (a.shape == (A, B)) and (A != B)
+        if soa and a.shape != (A, B):
+            raise ValueError(f"actions must have shape ({A}, {B}) for layout='soa', got {tuple(a.shape)}")
+        if not soa and a.shape != (B, A):
+            raise ValueError(f"actions must have shape ({A}, {B}) or ({B}, {A}), got {tuple(a.shape)}")
+        if soa and a.stride(1) == 1 and a.stride(0) >= B:
+            act, ld_act = a, a.stride(0)                      # native SoA, zero-copy
+        elif (not soa) and a.stride(0) == 1 and a.stride(1) >= B:
+            act, ld_act = a, a.stride(1)                      # [B,A] view of an SoA buffer, zero-copy
+        else:
+            self._act_soa[:, :B].copy_(a if soa else a.t())   # one transposing copy
+            act, ld_act = self._act_soa, self.ld
+        sn = self._noise(step_noise, int(self.spec.k_step)) if int(self.spec.k_step) else None
+        rn = self._noise(reset_noise, int(self.spec.k_reset))
+        ld_obs = 0
+        if final_obs is not None:
+            assert final_obs.dtype == torch.float32 and final_obs.shape[0] == self.state_dim and final_obs.stride(1) == 1
+            ld_obs = final_obs.stride(0)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_step(self._h, _ptr(act), ld_act, _ptr(sn), _ptr(rn), B,
+                                        _ptr(self.reward), _ptr(self.reward64), _ptr(self.flags),
+                                        _ptr(final_obs), ld_obs, self._stream()))
+        info = StepInfo(self.flags)
+        return self.obs, self.reward, info.terminated, info.truncated, info
+
+    def step_raw(self, act_soa: torch.Tensor, ld_act: int, reward=True, reward64=False, flags=True):
+        """Hot-loop form: no tensor conversions, no decoding; `act_soa` is float32 [A, >=B]."""
+        _lib.check(self._L.nig_step(self._h, C.c_void_p(act_soa.data_ptr()), ld_act, None, None, 0,
+                                    _ptr(self.reward) if reward else None,
+                                    _ptr(self.reward64) if reward64 else None,
+                                    _ptr(self.flags) if flags else None, None, 0, self._stream()))
+
+    def fill_actions(self, t: int, out: Optional[torch.Tensor] = None):
+        """Synthetic uniform [-1,1) actions of the bench workload for launch counter t -> [A, B]."""
+        if out is None:
+            out = torch.empty(self.action_dim, self.ld, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_fill_actions(self._h, C.c_uint32(t), _ptr(out), out.stride(0), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------
+    def set_state(self, state=None, current_step=None, violation_count=None, done=None):
+        """Teacher forcing: state [B,S] or [S,B]; counters optional (per-lane arrays)."""
+        B, S = self.batch, self.state_dim
+        st = None
+        if state is not None:
+            t = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+            st = (t.t() if t.shape == (B, S) else t).contiguous()    # [B,S] wins when B == S
+            assert st.shape == (S, B)
+        c = None
+        if current_step is not None or violation_count is not None or done is not None:
+            cs = torch.as_tensor(0 if current_step is None else current_step, device=self.device).to(torch.int64)
+            vc = torch.as_tensor(0 if violation_count is None else violation_count, device=self.device).to(torch.int64)
+            dn = torch.as_tensor(False if done is None else done, device=self.device).to(torch.int64)
+            word = (cs & _lib.CTR_STEP_MASK) | (dn * _lib.CTR_DONE) | ((vc & 0xFFFF) << _lib.CTR_VIOL_SHIFT)
+            word = torch.broadcast_to(word, (B,))
+            c = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32).contiguous()
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_set_state(self._h, _ptr(st), B, _ptr(c), self._stream()))
+
+    def get_state(self) -> torch.Tensor:
+        """A contiguous [B, S] copy of the current state."""
+        return self.obs.contiguous()
+
+    def get_safety_metrics(self):
+        """Per-lane SafetyMetrics fields of the last step as an int32 tensor [5, B]
+        (rows: constraints_satisfied, total_constraints, violation_count, critical_violations,
+        satisfied = safety_score * total)."""
+        out = torch.empty(5, self.batch, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_get_safety_metrics(self._h, _ptr(self.flags), _ptr(out), self.batch, self._stream()))
+        return out
+
+    def reduce_tally(self) -> torch.Tensor:
+        """Device reduction of the per-lane tallies -> float64 [T_ROWS] partial vector."""
+        out = torch.empty(_lib.T_ROWS, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_reduce_tally(self._h, _ptr(out), self._stream()))
+        return out

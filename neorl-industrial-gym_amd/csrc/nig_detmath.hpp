@@ -1,0 +1,211 @@
+// nig_detmath.hpp -- device-side deterministic math + counter-based RNG ("nig-philox-v1").
+//
+// Everything here is built from IEEE-754 + - * / sqrt only (file is compiled with
+// -ffp-contract=off, correctly-rounded division/sqrt), so a host evaluation of the same
+// operation sequence gives the same bits.  Specification: DESIGN.md "Deterministic math"
+// and "Synthetic input generator".  None of this exists in the reference (it draws from
+// NumPy's global MT19937, chemical_reactor.py:93-103,149,159; power_grid.py:98-108,
+// 136-144; robot_assembly.py:118-122): it is the workload generator of fast mode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nig {
+
+__device__ __forceinline__ float bits_f32(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
+
+// e^x, float32, Cephes-style: k = floor(x*log2e + 1/2), two-constant Cody-Waite, degree-5
+// polynomial, exact two-step scaling.  <= 1 ulp-ish; stands in for np.exp on float32
+// (chemical_reactor.py:177), which itself is only good to ~2 ulp.
+__device__ __forceinline__ float det_expf(float x)
+{
+    float fk = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - fk * 0.693359375f;
+    r = r - fk * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r;
+    p = p + 1.0f;
+    // clamp only affects the out-of-range inputs that are overridden below
+    fk = fminf(fmaxf(fk, -200.0f), 200.0f);
+    const int k = (int)fk;
+    const int k1 = k / 2, k2 = k - k1;
+    float res = (p * bits_f32((uint32_t)(k1 + 127) << 23)) * bits_f32((uint32_t)(k2 + 127) << 23);
+    res = (x < -103.0f) ? 0.0f : res;
+    res = (x > 88.72283f) ? __builtin_inff() : res;
+    res = (x != x) ? x : res;
+    return res;
+}
+
+// ln(x) for a normal float in (0,1] (argument is always k*2^-24, k >= 1).
+__device__ __forceinline__ float det_logf(float x)
+{
+    const uint32_t u = f32_bits(x);
+    int e = (int)(u >> 23) - 126;
+    float m = bits_f32((u & 0x007fffffu) | 0x3f000000u);   // [0.5, 1)
+    const bool lo = m < 0.707106781186547524f;
+    e = lo ? e - 1 : e;
+    m = lo ? (m + m - 1.0f) : (m - 1.0f);
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = y * m + -1.1514610310e-1f;
+    y = y * m + 1.1676998740e-1f;
+    y = y * m + -1.2420140846e-1f;
+    y = y * m + 1.4249322787e-1f;
+    y = y * m + -1.6668057665e-1f;
+    y = y * m + 2.0000714765e-1f;
+    y = y * m + -2.4999993993e-1f;
+    y = y * m + 3.3333331174e-1f;
+    y = y * m * z;
+    const float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    float r = m + y;
+    r = r + 0.693359375f * fe;
+    return r;
+}
+
+// sin, cos of 2*pi*k/2^24, k a 24-bit integer: octant from the top 3 bits (exact), then
+// degree-7 / degree-8 minimax polynomials on [0, pi/4].
+__device__ __forceinline__ void det_sincos2pi_u24(uint32_t k, float &s, float &c)
+{
+    const uint32_t oct = (k >> 21) & 7u;
+    uint32_t frac = k & 0x1fffffu;
+    frac = (oct & 1u) ? (0x200000u - frac) : frac;
+    const float x = (float)frac * (0.78539816339744830962f / 2097152.0f);
+    const float z = x * x;
+    float sp = -1.9515295891e-4f;
+    sp = sp * z + 8.3321608736e-3f;
+    sp = sp * z + -1.6666654611e-1f;
+    sp = sp * z * x + x;
+    float cp = 2.443315711809948e-5f;
+    cp = cp * z + -1.388731625493765e-3f;
+    cp = cp * z + 4.166664568298827e-2f;
+    cp = cp * z * z;
+    cp = cp + -0.5f * z;
+    cp = cp + 1.0f;
+    // octants 1,2,5,6 swap sin<->cos; sign of sin: octants 4-7; sign of cos: octants 2-5
+    const bool swap = ((oct + 1u) & 2u) != 0u;
+    float ss = swap ? cp : sp;
+    float cc = swap ? sp : cp;
+    ss = (oct & 4u) ? -ss : ss;
+    cc = ((oct + 2u) & 4u) ? -cc : cc;
+    s = ss; c = cc;
+}
+
+// double sin/cos for joint angles (|x| small multiples of pi): Cody-Waite with a 33-bit
+// pi/2 head (k*head exact), fdlibm kernel polynomials.  Stands in for np.sin/np.cos on
+// float64 scalars (robot_assembly.py:103-107).
+__device__ __forceinline__ void det_sincos(double x, double &s, double &c)
+{
+    const double fk = floor(x * 0.63661977236758134308 + 0.5);
+    double r = x - fk * 1.57079632673412561417e+00;
+    r = r - fk * 6.07710050650619224932e-11;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z + -2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z + -1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z + -1.66666666666666324348e-01;
+    const double sn = r + r * z * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z + -2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z + -1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    const double cs = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)((long long)fk & 3);
+    const bool swap = (q & 1) != 0;
+    double ss = swap ? cs : sn;
+    double cc = swap ? sn : cs;
+    ss = (q & 2) ? -ss : ss;
+    cc = ((q + 1) & 2) ? -cc : cc;
+    s = ss; c = cc;
+}
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter = (env_lo, env_hi, t, stream+block),
+// key = (seed_lo, seed_hi).
+// ---------------------------------------------------------------------------------
+constexpr uint32_t STREAM_STEP = 0u;
+constexpr uint32_t STREAM_RESET = 0x40000000u;
+constexpr uint32_t STREAM_ACTION = 0x80000000u;
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0;
+        const uint32_t n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+struct RngKey {
+    uint32_t env_lo, env_hi, t, seed_lo, seed_hi;
+    __device__ __forceinline__ u32x4 block(uint32_t stream_block) const
+    {
+        return philox4x32_10(env_lo, env_hi, t, stream_block, seed_lo, seed_hi);
+    }
+};
+
+// two standard normals from two words: Box-Muller on 24-bit uniforms
+__device__ __forceinline__ void bm_pair(uint32_t x0, uint32_t x1, float &z0, float &z1)
+{
+    const float u1 = (float)((x0 >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * det_logf(u1));
+    float s, c;
+    det_sincos2pi_u24(x1 >> 8, s, c);
+    z0 = r * c; z1 = r * s;
+}
+
+__device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+
+// N standard normals of stream `stream` into z[0..N) (compile-time N, fully unrolled)
+template <int N>
+__device__ __forceinline__ void gen_normals(const RngKey &k, uint32_t stream, float (&z)[N])
+{
+#pragma unroll
+    for (int j = 0; 4 * j < N; ++j) {
+        const u32x4 x = k.block(stream + (uint32_t)j);
+        float a, b, c, d;
+        bm_pair(x.x, x.y, a, b);
+        if (4 * j + 0 < N) z[4 * j + 0] = a;
+        if (4 * j + 1 < N) z[4 * j + 1] = b;
+        if (4 * j + 2 < N) {
+            bm_pair(x.z, x.w, c, d);
+            z[4 * j + 2] = c;
+            if (4 * j + 3 < N) z[4 * j + 3] = d;
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void gen_uniforms(const RngKey &k, uint32_t stream, double (&u)[N])
+{
+#pragma unroll
+    for (int j = 0; 4 * j < N; ++j) {
+        const u32x4 x = k.block(stream + (uint32_t)j);
+        if (4 * j + 0 < N) u[4 * j + 0] = u01(x.x);
+        if (4 * j + 1 < N) u[4 * j + 1] = u01(x.y);
+        if (4 * j + 2 < N) u[4 * j + 2] = u01(x.z);
+        if (4 * j + 3 < N) u[4 * j + 3] = u01(x.w);
+    }
+}
+
+}  // namespace nig

@@ -1,0 +1,337 @@
+"""Single-environment drop-in classes: the reference's IndustrialEnv surface
+(environments/base.py:19-228) over ONE lane of the HIP batch kernel.
+
+`ni.make('ChemicalReactor-v0')` returns one of these.  The arithmetic of reset/step runs
+on the GPU through libnig.so; this file is host glue only: it draws the process noise
+from NumPy's global RNG in exactly the reference's call order (so `np.random.seed(k)`
+reproduces the reference's trajectories), moves ~100 bytes per step, and rebuilds the
+reference's `info` dict / SafetyMetrics objects from the kernel's flag word.
+For throughput use BatchedIndustrialEnv (ni.make_batched); this class exists so existing
+single-env callers (agents, harnesses, evaluate_with_safety) run unchanged.
+"""
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batched import BatchedIndustrialEnv
+from .core import SafetyConstraint, SafetyMetrics
+
+f32 = np.float32
+
+
+class IndustrialEnv:
+    """Host mirror of environments/base.py:19-228 (one env instance, B = 1)."""
+
+    ENV_ID: str = ""
+
+    def __init__(self, max_episode_steps: Optional[int] = None, dt: Optional[float] = None,
+                 device="cuda:0", noise: str = "numpy", seed: int = 0x5EED):
+        if noise not in ("numpy", "device"):
+            raise ValueError("noise must be 'numpy' (reference-compatible global np.random) or 'device'")
+        self._noise_mode = noise
+        self._b = BatchedIndustrialEnv(self.ENV_ID, 1, device=device, seed=seed, max_episode_steps=max_episode_steps,
+                                       dt=dt, autoreset=False, tally=False)
+        sp = self._b.spec
+        self.state_dim, self.action_dim = self._b.state_dim, self._b.action_dim       # base.py:41-42
+        self.max_episode_steps, self.dt = self._b.max_episode_steps, self._b.dt       # base.py:43-44
+        self._builtin = self._builtin_constraints()
+        assert len(self._builtin) == int(sp.n_constraints)
+        self.safety_constraints: List[SafetyConstraint] = list(self._builtin)          # base.py:47
+        self.current_step = 0                                                          # base.py:50-53
+        self.state = None
+        self.done = False
+        self.info: Dict[str, Any] = {}
+        self.violation_count = 0                                                       # base.py:56-57
+        self.total_violations = 0
+        self.observation_space = self._b.observation_space                             # base.py:60-72
+        self.action_space = self._b.action_space
+        self._last_metrics: Optional[SafetyMetrics] = None
+        self._state_host = torch.empty(1, self.state_dim, dtype=torch.float32).pin_memory()
+        self._needs_reset = True
+
+    # -- per-env host pieces (overridden) --------------------------------------
+    def _builtin_constraints(self) -> List[SafetyConstraint]:
+        raise NotImplementedError
+
+    def _draw_reset_noise(self) -> np.ndarray:
+        raise NotImplementedError
+
+    def _draw_step_noise(self) -> Optional[np.ndarray]:
+        raise NotImplementedError
+
+    def _get_safety_info(self, state) -> Dict[str, Any]:
+        """base.py:126-131"""
+        return {"safety_metrics": {}, "constraint_values": {}}
+
+    # -- helpers ---------------------------------------------------------------
+    def _pull_state(self) -> np.ndarray:
+        self._state_host.copy_(self._b.obs)          # D2H of S floats (synchronises the stream)
+        return self._state_host.numpy()[0].copy()
+
+    def _sync_constraint_mask(self):
+        names = {c.name for c in self.safety_constraints}
+        mask = 0
+        for k, c in enumerate(self._builtin):
+            # a built-in stays on the device only while the identical object is still in the list
+            if any(c is x for x in self.safety_constraints):
+                mask |= 1 << k
+        del names
+        self._b.set_constraint_mask(mask)
+        return mask
+
+    # -- API -------------------------------------------------------------------
+    def reset(self, *, seed: Optional[int] = None, options: Optional[Dict] = None) -> Tuple[np.ndarray, Dict]:
+        """base.py:133-155.  As upstream, `seed` does not touch the global np.random stream the
+        envs draw from (gymnasium's Env.reset only seeds self.np_random)."""
+        self.current_step = 0
+        self.done = False
+        self.violation_count = 0
+        if self._noise_mode == "numpy":
+            nz = self._draw_reset_noise().reshape(-1, 1)
+            self._b.reset(init_noise=nz)
+        else:
+            self._b.reset()
+        self.state = self._pull_state()
+        self._needs_reset = False
+        obs = self.state.copy()
+        info = self._get_safety_info(self.state)
+        info.update({"step": self.current_step, "violations": self.violation_count,
+                     "total_violations": self.total_violations})
+        return obs, info
+
+    def step(self, action) -> Tuple[np.ndarray, Any, bool, bool, Dict]:
+        """base.py:157-213"""
+        if self.done or self._needs_reset:
+            raise RuntimeError("Environment is done. Call reset() first.")
+        action = np.asarray(action)
+        a32 = action.astype(np.float32, copy=False).reshape(self.action_dim)
+        a_clip = np.clip(a32, self.action_space.low, self.action_space.high)       # base.py:167
+        state_pre = self.state
+        mask = self._sync_constraint_mask()
+        custom = [c for c in self.safety_constraints if not any(c is b for b in self._builtin)]
+
+        sn = None
+        if self._noise_mode == "numpy":
+            sn = self._draw_step_noise()
+            sn = None if sn is None else sn.reshape(-1, 1)
+        # parity mode without step noise (RobotAssembly draws none): still deterministic
+        self._b.step(torch.from_numpy(a32.reshape(self.action_dim, 1)), step_noise=sn, layout="soa")
+        new_state = self._pull_state()
+        flags = int(self._b.flags.item())
+        reward64 = float(self._b.reward64.item())
+        reward: Any = f32(reward64) if int(self._b.spec.reward_is_f32) else reward64
+
+        nv = (flags >> _lib.FLAG_NVIOL_SHIFT) & 3
+        nc = (flags >> _lib.FLAG_NCRIT_SHIFT) & 3
+        terminated = bool(flags & _lib.FLAG_TERMINATED)
+        truncated = bool(flags & _lib.FLAG_TRUNCATED)
+        n_total = len(self.safety_constraints)
+        satisfied = bin(mask).count("1") - nv
+        viol, crit = nv, nc
+
+        # constraints added by the user are arbitrary Python callables (base.py:220-222): they are
+        # evaluated here on the pre-state exactly as base.py:94-124 / 179-183 do, after the built-ins
+        custom_crit = 0
+        for c in custom:
+            try:
+                ok = bool(c.check_fn(state_pre, a_clip))
+            except Exception:
+                ok = False
+            if ok:
+                satisfied += 1
+            else:
+                viol += 1
+                if c.critical:
+                    crit += 1
+                    custom_crit += 1
+        if custom:
+            extra_count = 0
+            for c in custom:           # base.py:179-183 second evaluation; exceptions propagate upstream too
+                if not c.check_fn(state_pre, a_clip):
+                    reward = reward + c.penalty
+                    extra_count += 1
+            if custom_crit > 0 and nc == 0:
+                terminated = True
+                reward = reward - 1000.0
+                self._b.set_state(current_step=self.current_step + 1,
+                                  violation_count=self.violation_count + nv + extra_count, done=True)
+            self.violation_count += extra_count
+            self.total_violations += extra_count
+
+        self.violation_count += nv
+        self.total_violations += nv
+        self.state = new_state
+        self.current_step += 1
+        self.done = terminated or truncated
+        safety_metrics = SafetyMetrics(
+            constraints_satisfied=satisfied, total_constraints=n_total, violation_count=viol,
+            critical_violations=crit, safety_score=(satisfied / n_total) if n_total > 0 else 1.0)
+        self._last_metrics = safety_metrics
+        obs = self.state.copy()
+        info = self._get_safety_info(self.state)
+        info.update({"step": self.current_step, "violations": self.violation_count,
+                     "total_violations": self.total_violations, "safety_metrics": safety_metrics,
+                     "critical_shutdown": crit > 0})
+        return obs, reward, terminated, truncated, info
+
+    def get_safety_metrics(self) -> SafetyMetrics:
+        """Named by the reference README / callers (benchmarks/industrial_benchmarks.py:148) but only
+        defined upstream on the non-instantiable Advanced envs; here: SafetyMetrics of the last step."""
+        if self._last_metrics is None:
+            n = len(self.safety_constraints)
+            return SafetyMetrics(constraints_satisfied=n, total_constraints=n, violation_count=0,
+                                 critical_violations=0, safety_score=1.0)
+        return self._last_metrics
+
+    def add_safety_constraint(self, constraint: SafetyConstraint) -> None:
+        """base.py:220-222"""
+        self.safety_constraints.append(constraint)
+
+    def remove_safety_constraint(self, name: str) -> None:
+        """base.py:224-228"""
+        self.safety_constraints = [c for c in self.safety_constraints if c.name != name]
+
+    def get_dataset(self, quality: str = "mixed"):
+        """base.py:215-218 -- dataset generation is a 'next' row of the scope table."""
+        from .datasets import get_dataset
+        return get_dataset(self, quality)
+
+    def close(self):
+        self._b.close()
+
+
+class ChemicalReactorEnv(IndustrialEnv):
+    """environments/chemical_reactor.py:11-87"""
+    ENV_ID = "ChemicalReactor-v0"
+
+    def __init__(self, **kwargs):
+        if "max_episode_steps" in kwargs or "dt" in kwargs:
+            # upstream passes both positionally AND **kwargs to super().__init__ (chemical_reactor.py:62-69)
+            raise TypeError("ChemicalReactorEnv() got multiple values for keyword argument "
+                            "'max_episode_steps' or 'dt' (hard-coded to 500 / 0.1 upstream)")
+        super().__init__(**kwargs)
+        self.temp_min, self.temp_max, self.temp_target = 280.0, 350.0, 320.0            # :72-74
+        self.pressure_min, self.pressure_max, self.pressure_target = 101325.0, 506625.0, 253312.5   # :76-78
+        self.reaction_rate_constant, self.heat_capacity, self.reactor_volume = 0.1, 4.18e3, 1000.0  # :81-83
+        self.temp_noise_std, self.pressure_noise_std = 1.0, 5000.0                      # :86-87
+
+    def _builtin_constraints(self):
+        return [   # chemical_reactor.py:38-60
+            SafetyConstraint("temperature_limit", self._temperature_constraint, -100.0, True,
+                             "Reactor temperature must stay below 350K"),
+            SafetyConstraint("pressure_limit", self._pressure_constraint, -50.0, True,
+                             "Reactor pressure must stay below 5 atm"),
+            SafetyConstraint("level_safety", self._level_constraint, -25.0, False,
+                             "Reactor level must stay between 20-90%"),
+        ]
+
+    # host restatements for introspection only (the device evaluates the built-ins), :292-305
+    def _temperature_constraint(self, state, action) -> bool:
+        temp = state[0] if len(state.shape) == 1 else state[0, 0]
+        return bool(temp <= 350.0)
+
+    def _pressure_constraint(self, state, action) -> bool:
+        pressure = state[1] if len(state.shape) == 1 else state[1, 0]
+        return bool(pressure <= 506625.0)
+
+    def _level_constraint(self, state, action) -> bool:
+        level = state[10] if len(state.shape) == 1 else state[10, 0]
+        return bool(20 <= level <= 90)
+
+    def _draw_reset_noise(self):   # call order of chemical_reactor.py:93-103
+        n = np.random.normal
+        return np.array([n(0, 2), n(0, 10000), n(0, 5), n(0, 3), n(0, 0.1), n(0, 2), n(0, 1), n(0, 5)],
+                        dtype=np.float64)
+
+    def _draw_step_noise(self):    # chemical_reactor.py:149,159
+        return np.array([np.random.normal(0, 1.0 / 10), np.random.normal(0, 5000.0 / 10)], dtype=np.float64)
+
+    def _get_safety_info(self, state):   # chemical_reactor.py:307-322
+        return {
+            "safety_metrics": {"temperature": state[0], "pressure": state[1], "level": state[10],
+                               "emergency_stop": state[8], "alarm_status": state[9]},
+            "constraint_values": {"temp_margin": self.temp_max - state[0],
+                                  "pressure_margin": self.pressure_max - state[1],
+                                  "level_in_bounds": 20 <= state[10] <= 90},
+        }
+
+
+def _pg_frequency_constraint(state, action) -> bool:      # power_grid.py:10-14
+    return bool(abs(state[0]) < 0.5)
+
+
+def _pg_voltage_constraint(state, action) -> bool:        # power_grid.py:17-21
+    v = state[1:9]
+    return bool(np.all((v >= 0.95) & (v <= 1.05)))
+
+
+def _pg_generation_constraint(state, action) -> bool:     # power_grid.py:24-30
+    new_gen = state[9:17] + action
+    return bool(np.all((new_gen >= 0) & (new_gen <= np.ones(8) * 100)))
+
+
+class PowerGridEnv(IndustrialEnv):
+    """environments/power_grid.py:33-88"""
+    ENV_ID = "PowerGrid-v0"
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.base_load = np.array([50, 60, 45, 55, 40, 65, 35, 50])                     # :82
+        self.load_variation, self.inertia_constant, self.damping_factor = 0.2, 5.0, 1.0  # :83-85
+        self.generation_cost = np.array([25, 30, 28, 35, 32, 27, 40, 33])               # :88
+
+    def _builtin_constraints(self):
+        return [   # power_grid.py:53-72
+            SafetyConstraint("frequency_stability", _pg_frequency_constraint, -50.0, True),
+            SafetyConstraint("voltage_limits", _pg_voltage_constraint, -30.0, True),
+            SafetyConstraint("generation_limits", _pg_generation_constraint, -20.0, False),
+        ]
+
+    def _draw_reset_noise(self):   # power_grid.py:98-108
+        return np.concatenate([np.random.normal(0, 0.01, 8), np.random.normal(0, 2, 8),
+                               np.random.uniform(-0.2, 0.2, 8), np.random.normal(0, 10, 7)])
+
+    def _draw_step_noise(self):    # power_grid.py:136,140,144
+        return np.concatenate([np.random.normal(0, 0.005, 8), np.random.normal(0, 1, 8),
+                               np.random.normal(0, 2, 7)])
+
+
+def _ra_force_constraint(state, action) -> bool:          # robot_assembly.py:10-15
+    return bool(np.all(np.abs(state[18:21]) < 50.0))
+
+
+def _ra_collision_constraint(state, action) -> bool:      # robot_assembly.py:18-25
+    p = state[0:3]
+    return bool(np.all((p >= np.array([-0.5, -0.5, 0.0])) & (p <= np.array([0.5, 0.5, 0.8]))))
+
+
+def _ra_velocity_constraint(state, action) -> bool:       # robot_assembly.py:28-32
+    return bool(np.all(np.abs(state[7:14]) < 2.0))
+
+
+class RobotAssemblyEnv(IndustrialEnv):
+    """environments/robot_assembly.py:35-92"""
+    ENV_ID = "RobotAssembly-v0"
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.link_lengths = np.array([0.3, 0.3, 0.25, 0.25, 0.15, 0.1, 0.05])           # :85
+        self.joint_limits_low = np.array([-np.pi] * 7)                                  # :86-87
+        self.joint_limits_high = np.array([np.pi] * 7)
+        self.target_position = np.array([0.3, 0.0, 0.4])                                # :90
+        self.insertion_depth, self.alignment_tolerance = 0.05, 0.005                    # :91-92
+
+    def _builtin_constraints(self):
+        return [   # robot_assembly.py:56-75
+            SafetyConstraint("force_limits", _ra_force_constraint, -100.0, True),
+            SafetyConstraint("collision_avoidance", _ra_collision_constraint, -200.0, True),
+            SafetyConstraint("velocity_limits", _ra_velocity_constraint, -50.0, False),
+        ]
+
+    def _draw_reset_noise(self):   # robot_assembly.py:118-122
+        return np.random.uniform(np.array([-np.pi] * 7) * 0.5, np.array([np.pi] * 7) * 0.5, 7)
+
+    def _draw_step_noise(self):    # deterministic step
+        return None

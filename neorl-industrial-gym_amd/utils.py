@@ -1,0 +1,132 @@
+"""make / make_batched / evaluate_with_safety -- mirror of neorl_industrial/utils.py."""
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batched import BatchedIndustrialEnv
+from .envs import ChemicalReactorEnv, PowerGridEnv, RobotAssemblyEnv
+from .parallel import all_reduce_partial, metrics_from_partial
+
+_REGISTRY = {
+    "ChemicalReactor-v0": ChemicalReactorEnv,
+    "PowerGrid-v0": PowerGridEnv,
+    "RobotAssembly-v0": RobotAssemblyEnv,
+}
+
+
+def make(env_id: str, **kwargs) -> Any:
+    """utils.py:12-39.  Unknown ids raise the reference's ValueError text.  The two
+    'Advanced*' ids of the upstream registry cannot be instantiated upstream either
+    (abstract methods missing, SURVEY.md finding 2) and are not registered here."""
+    if env_id not in _REGISTRY:
+        available = ", ".join(_REGISTRY.keys())
+        raise ValueError(f"Unknown environment '{env_id}'. Available: {available}")
+    return _REGISTRY[env_id](**kwargs)
+
+
+def make_batched(env_id: str, batch: int, **kwargs) -> BatchedIndustrialEnv:
+    """B independent instances of `env_id` on one GPU (no upstream equivalent: the reference
+    has no vectorised env)."""
+    return BatchedIndustrialEnv(env_id, batch, **kwargs)
+
+
+def _predict(agent, obs_dev: torch.Tensor) -> torch.Tensor:
+    """agent.predict contract (agents/base.py:106-141): float32 [n,S] -> float32 [n,A].
+    An agent exposing `predict_device(obs_tensor)` is called without leaving the GPU."""
+    if hasattr(agent, "predict_device"):
+        return agent.predict_device(obs_dev)
+    obs = obs_dev.contiguous().cpu().numpy()
+    act = agent.predict(obs, deterministic=True)
+    return torch.as_tensor(np.asarray(act, dtype=np.float32))
+
+
+def evaluate_with_safety(agent: Any, env: Any, n_episodes: int = 100, record_video: bool = False,
+                         render: bool = False, step_noise_fn=None, reset_noise_fn=None) -> Dict[str, Any]:
+    """utils.py:42-154.  With a single env this is the reference's loop verbatim in behaviour;
+    with a BatchedIndustrialEnv (created with tally=True, autoreset=False) the n_episodes
+    episodes run in parallel lanes and the 13 aggregates come from the device tallies."""
+    if not hasattr(agent, "is_trained") or not agent.is_trained:
+        raise RuntimeError("Agent must be trained before evaluation")
+    if isinstance(env, BatchedIndustrialEnv):
+        return _evaluate_batched(agent, env, n_episodes, step_noise_fn, reset_noise_fn)
+
+    episode_returns, episode_lengths = [], []
+    total_violations = critical_violations = emergency_shutdowns = 0
+    constraint_satisfaction_rates = []
+    for _ in range(n_episodes):
+        obs, info = env.reset()
+        episode_return = 0.0
+        episode_length = episode_violations = episode_critical = episode_shutdowns = 0
+        done = False
+        while not done:
+            action = agent.predict(obs[None], deterministic=True)[0]
+            next_obs, reward, terminated, truncated, info = env.step(action)
+            done = terminated or truncated
+            episode_return += reward
+            episode_length += 1
+            if "safety_metrics" in info:
+                sm = info["safety_metrics"]
+                episode_violations += sm.violation_count
+                episode_critical += sm.critical_violations
+                constraint_satisfaction_rates.append(sm.satisfaction_rate)
+            if info.get("critical_shutdown", False):
+                episode_shutdowns += 1
+            obs = next_obs
+            if render:
+                try:
+                    env.render()
+                except Exception:
+                    pass
+        episode_returns.append(episode_return)
+        episode_lengths.append(episode_length)
+        total_violations += episode_violations
+        critical_violations += episode_critical
+        emergency_shutdowns += episode_shutdowns
+    return {
+        "return_mean": np.mean(episode_returns), "return_std": np.std(episode_returns),
+        "return_min": np.min(episode_returns), "return_max": np.max(episode_returns),
+        "length_mean": np.mean(episode_lengths), "length_std": np.std(episode_lengths),
+        "safety_violations": total_violations,
+        "safety_violations_per_episode": total_violations / n_episodes,
+        "critical_violations": critical_violations, "emergency_shutdowns": emergency_shutdowns,
+        "constraint_satisfaction_rate": (np.mean(constraint_satisfaction_rates)
+                                         if constraint_satisfaction_rates else 1.0),
+        "successful_episodes": sum(1 for r in episode_returns if r > 0),
+        "success_rate": sum(1 for r in episode_returns if r > 0) / n_episodes,
+    }
+
+
+def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_noise_fn=None, reset_noise_fn=None,
+                      group=None, reduce_across_ranks: bool = True) -> Dict[str, Any]:
+    """Episodes in parallel lanes.  Rounds of up to B episodes: reset the needed lanes, step
+    until every one of them is done (finished lanes are frozen by the kernel), tallies
+    accumulate on the device; one reduction (+ all-gather across ranks) at the end.
+
+    step_noise_fn(round, t) / reset_noise_fn(round) may supply recorded draws (parity tests)."""
+    if not env.tally_enabled or env.autoreset:
+        raise ValueError("batched evaluation needs make_batched(..., tally=True, autoreset=False)")
+    B = env.batch
+    remaining, rnd = int(n_episodes), 0
+    while remaining > 0:
+        k = min(B, remaining)
+        mask = torch.zeros(B, dtype=torch.uint8, device=env.device)
+        mask[:k] = 1
+        env.reset(mask=mask, init_noise=None if reset_noise_fn is None else reset_noise_fn(rnd))
+        t = 0
+        while True:
+            act = _predict(agent, env.obs)
+            env.step(act, step_noise=None if step_noise_fn is None else step_noise_fn(rnd, t), layout="aos")
+            t += 1
+            if bool(env.done.all().item()) or t > _lib.MAX_EPISODE_STEPS:
+                break
+        remaining -= k
+        rnd += 1
+    partial = env.reduce_tally()
+    total = all_reduce_partial(partial, group) if reduce_across_ranks else partial
+    import torch.distributed as dist
+    n_total = n_episodes
+    if reduce_across_ranks and dist.is_available() and dist.is_initialized():
+        n_total = int(round(float(total[_lib.T_EPISODES].item())))
+    return metrics_from_partial(total, n_total)

@@ -1,0 +1,86 @@
+"""not-gpu: the C-ABI shared library loads, exports every symbol include/nig.h declares,
+answers the static queries, and refuses to run without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "nig.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nig_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import neorl_industrial_gym_amd as ni
+    L = ni._lib.lib()
+    names = _header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"libnig.so does not export {n}"
+    assert sorted(ni._lib.SYMBOLS) == names, "binding list and header disagree"
+
+
+def test_static_queries_match_reference_constants(oracle):
+    import neorl_industrial_gym_amd as ni
+    L = ni._lib.lib()
+    assert L.nig_version().decode().startswith("nig ")
+    want = {"ChemicalReactor-v0": (0, 12, 3, 500, 2, 8), "PowerGrid-v0": (1, 32, 8, 1000, 23, 31),
+            "RobotAssembly-v0": (2, 24, 7, 1000, 0, 7)}
+    for name, (eid, S, A, T, ks, kr) in want.items():
+        assert L.nig_env_id(name.encode()) == eid
+        assert L.nig_env_name(eid).decode() == name
+        sp = ni._lib.env_spec(eid)
+        assert (sp.state_dim, sp.action_dim, sp.max_episode_steps, sp.k_step, sp.k_reset) == (S, A, T, ks, kr)
+        osp = oracle.spec(name)
+        assert list(sp.penalty) == list(osp.penalty) and list(sp.critical) == list(osp.critical)
+        assert sp.dt == osp.dt == 0.1 and sp.n_constraints == 3
+    assert L.nig_env_id(b"AdvancedChemicalReactor-v0") == -1
+    assert L.nig_env_id(b"nope") == -1
+
+
+def test_layout_query():
+    import neorl_industrial_gym_amd as ni
+    lay = ni._lib.layout_query(1, 1000, ni._lib.F_TALLY)
+    assert lay.batch == 1000 and lay.ld == 1024 and lay.off_state == 0
+    assert lay.off_ctr >= 32 * 1024 * 4 and lay.off_tally > lay.off_ep_return > lay.off_life_viol > lay.off_ctr
+    assert lay.bytes % 256 == 0
+    lay2 = ni._lib.layout_query(1, 1000, 0)
+    assert lay2.off_tally == -1 and lay2.off_ep_return == -1 and lay2.bytes < lay.bytes
+    with pytest.raises(ni._lib.NigError):
+        ni._lib.layout_query(7, 10, 0)
+    with pytest.raises(ni._lib.NigError):
+        ni._lib.layout_query(0, 0, 0)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly (never route through the oracle)."""
+    import torch
+    import neorl_industrial_gym_amd as ni
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = ni._lib.lib()
+    h = C.c_void_p()
+    rc = L.nig_create(0, 16, 0, 1, 0, 0, C.c_double(0.0), 0, None, C.byref(h))
+    assert rc == 3 and not h.value          # NIG_ERR_NODEVICE
+    assert b"no CPU fallback" in L.nig_last_error()
+    with pytest.raises(RuntimeError):
+        ni.make("ChemicalReactor-v0")
+    with pytest.raises(RuntimeError):
+        ni.make_batched("PowerGrid-v0", 8)
+    with pytest.raises(ValueError, match="Unknown environment 'Foo-v0'. Available: ChemicalReactor-v0"):
+        ni.make("Foo-v0")
+
+
+def test_product_never_imports_oracle():
+    """Static guard: no file of the shipped package mentions the oracle directory."""
+    pkg = os.path.join(ROOT, "neorl-industrial-gym_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "nig_oracle" not in txt, f
