@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the IndustrialEnv.step() hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE).
+A "step" = one IndustrialEnv.step() of every lane of the batch (one launch of the fused step
+kernel).  Workload at N=1 = BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs,
+uniform random float32 actions from a pre-filled on-device ring, process noise and auto-reset
+drawn in-kernel from the counter-based generator (synthetic data).  Every rank
+runs the same per-GPU batch (weak scaling); lanes are keyed by global index; the only
+collective is the all-gather of the 11-double episode tally after the timed region.
+
+One JSON line on rank 0:  metric/value/unit/... + "roofline" + "cpu_baseline" (+ "parity").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS = {"cr": "ChemicalReactor-v0", "pg": "PowerGrid-v0", "ra": "RobotAssembly-v0"}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def alg_bytes_per_step(S, A):
+    """SURVEY.md 8(d), step-API mode: state R + state/obs W + action R + reward W + flags W +
+    counter R+W = 8*S + 4*A + 16 bytes per env-step (episode accumulators not counted)."""
+    return 8 * S + 4 * A + 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--env", default="cr", choices=list(ENVS))
+    ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--plan-steps", type=int, default=100, help="steps recorded per hipGraph replay")
+    ap.add_argument("--ring", type=int, default=64, help="slots of the pre-filled action ring")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL
+
+    import neorl_industrial_gym_amd as ni
+
+    key = args.env
+    B = args.batch or {"cr": 65536, "pg": 262144, "ra": 262144}[key]
+    seed = 0x5EED
+    env = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=rank * B, autoreset=True, tally=True)
+    S, A = env.state_dim, env.action_dim
+
+    # ---- parity probe (rank 0): the workload's first steps against the CPU oracle, bit for bit
+    parity = None
+    if rank == 0 and not args.no_parity:
+        from oracle import oracle as O
+        Tp = 32
+        penv = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=0, autoreset=True)
+        penv.reset()
+        viol = torch.zeros((), dtype=torch.int64, device=device)
+        crit = torch.zeros((), dtype=torch.int64, device=device)
+        pact = torch.empty(A, penv.ld, dtype=torch.float32, device=device)
+        for t in range(1, Tp + 1):
+            penv.fill_actions(t, pact)
+            _, _, _, _, info = penv.step(pact[:, :B], layout="soa")
+            viol += info.violation_count.sum()
+            crit += info.critical_violations.sum()
+        st, sc, tot, _ = O.rollout(key, B, Tp, seed=seed, flavor=O.MATH_POLY, nthreads=min(os.cpu_count() or 1, 32))
+        same = bool(np.array_equal(penv.get_state().cpu().numpy().view(np.uint32), st.view(np.uint32)))
+        parity = {"lanes": B, "steps": Tp, "violations_gpu": int(viol.item()), "violations_cpu": int(tot.violations),
+                  "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical), "state_bits_equal": same}
+        penv.close()
+        del penv
+
+    # ---- workload: action ring resident in HBM before the timed region
+    R = args.ring
+    ring = torch.empty(R, A, env.ld, dtype=torch.float32, device=device)
+    for s in range(R):
+        env.fill_actions(1000 + s, ring[s])
+    env.reset()
+    P = max(1, min(args.plan_steps, args.steps)) if args.mode == "graph" else 1
+    plan = env.make_plan(P, ring) if args.mode == "graph" else None
+
+    def run(n):
+        full, rem = (divmod(n, P) if plan is not None else (0, n))
+        for _ in range(full):
+            plan.launch()
+        for k in range(rem):
+            env.step_raw(ring[k % R], env.ld, reward=False, flags=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(); barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall, dev_ms = float(tmax[0].item()), float(tmax[1].item())
+
+    # ---- the path's one exchange: final tally reduction (after the timed region)
+    from neorl_industrial_gym_amd.parallel import all_reduce_partial
+    total = all_reduce_partial(env.reduce_tally()).cpu().numpy()
+    L = ni._lib
+
+    if rank == 0:
+        steps_total = args.steps * B * world
+        value = steps_total / wall
+        bytes_step = alg_bytes_per_step(S, A)
+        launch_us = dev_ms * 1e3 / args.steps                   # HIP events over the timed region / launches
+        achieved = bytes_step * B / (launch_us * 1e-6) / 1e9    # GB/s, algorithmic bytes per launch / launch time
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{key}_{B}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) + safety-violation-count parity, ChemicalReactor-v0"
+                      if key == "cr" else f"env-steps/sec (whole node), {ENVS[key]}",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU, step-API (one fused "
+                                   f"step kernel per env.step), {args.mode} launch"
+                                   + (f" ({P} steps per hipGraph replay)" if plan is not None else ""),
+                       "batch_per_gpu": B, "global_batch": B * world, "action_ring": R,
+                       "autoreset": True, "episode_tally": True,
+                       "parallelism": f"env-shard x{world} (no data-path collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "step_kernel<%s,false>" % {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}[key],
+                         "alg_bytes_per_env_step": bytes_step, "alg_bytes_per_launch": bytes_step * B,
+                         "launch_us": launch_us},
+            "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
+                      "critical": int(total[L.T_CRIT]), "return_mean": float(total[L.T_RET_SUM] / max(total[L.T_EPISODES], 1))},
+        }
+        if parity is not None:
+            out["parity"] = parity
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            cores = max(1, min(os.cpu_count() or 1, 64))
+            try:
+                cores = min(cores, len(os.sched_getaffinity(0)))
+            except Exception:
+                pass
+            # calibrate, then a bounded sample of the SAME workload (same lanes, seeds, policy, auto-reset)
+            c0 = time.perf_counter()
+            O.rollout(key, B, 4, seed=seed, flavor=O.MATH_LIBM, nthreads=cores)
+            per_step = (time.perf_counter() - c0) / 4
+            Tc = int(max(8, min(2000, args.cpu_seconds / max(per_step, 1e-6))))
+            c0 = time.perf_counter()
+            _, _, tot, _ = O.rollout(key, B, Tc, seed=seed, flavor=O.MATH_LIBM, nthreads=cores)
+            cw = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": tot.steps / cw, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                   "sample": f"{B} lanes x {Tc} steps of the same workload (oracle/nig_oracle.c, "
+                                             f"OpenMP over lanes, libm math), {cw:.2f} s wall"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

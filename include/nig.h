@@ -180,6 +180,24 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act,
              float *reward_out, double *reward64_out, uint32_t *flags_out,
              float *final_obs, int64_t ld_obs, void *stream);
 
+/*
+ * A plan = n_steps consecutive nig_step launches in fast mode recorded once as a hipGraph
+ * and replayed with one call (the per-step launch is otherwise host-bound at small batch).
+ * Step k (0-based) of every replay reads its actions from ring slot k % ring_len:
+ *   action_ring  float, slot s at action_ring + s*slot_stride, each slot [A][ld_act]
+ *   reward_out / flags_out  optional; slot s at base + s*out_stride (out_stride 0 = every
+ *                step overwrites the same [B] array)
+ * Semantics per step are exactly nig_step's (same kernel); the launch counter advances by
+ * n_steps per replay.  This is the shape of the reference's own measurement loop
+ * (performance_benchmark.py:106-133: sample action -> step -> reset on done).
+ */
+typedef struct nig_plan nig_plan;
+int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act,
+                    int64_t slot_stride, int32_t ring_len, float *reward_out, uint32_t *flags_out,
+                    int64_t out_stride, nig_plan **out);
+int nig_plan_launch(nig_plan *p, void *stream);
+int nig_plan_destroy(nig_plan *p);
+
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);

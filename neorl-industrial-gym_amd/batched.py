@@ -270,6 +270,12 @@ class BatchedIndustrialEnv:
                                     _ptr(self.reward64) if reward64 else None,
                                     _ptr(self.flags) if flags else None, None, 0, self._stream()))
 
+    def make_plan(self, n_steps: int, action_ring: torch.Tensor, reward_ring: Optional[torch.Tensor] = None,
+                  flags_ring: Optional[torch.Tensor] = None) -> "StepPlan":
+        """Record n_steps fast-mode steps as one hipGraph.  action_ring: float32 [R, A, ld>=B];
+        step k of every replay reads slot k % R.  Optional reward/flags rings [R, B] (or [B])."""
+        return StepPlan(self, n_steps, action_ring, reward_ring, flags_ring)
+
     def fill_actions(self, t: int, out: Optional[torch.Tensor] = None):
         """Synthetic uniform [-1,1) actions of the bench workload for launch counter t -> [A, B]."""
         if out is None:
@@ -317,3 +323,44 @@ class BatchedIndustrialEnv:
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.nig_reduce_tally(self._h, _ptr(out), self._stream()))
         return out
+
+
+class StepPlan:
+    """n consecutive env.step() launches replayed as one hipGraph (include/nig.h nig_plan_*)."""
+
+    def __init__(self, env: BatchedIndustrialEnv, n_steps: int, action_ring: torch.Tensor,
+                 reward_ring: Optional[torch.Tensor], flags_ring: Optional[torch.Tensor]):
+        assert action_ring.dtype == torch.float32 and action_ring.dim() == 3 and action_ring.stride(2) == 1
+        R, A, ld = action_ring.shape[0], action_ring.shape[1], action_ring.stride(1)
+        assert A == env.action_dim and ld >= env.batch
+        self.env, self.n_steps = env, int(n_steps)
+        self._keep = (action_ring, reward_ring, flags_ring)
+
+        def out(t, dtype):
+            if t is None:
+                return None, 0
+            assert t.dtype == dtype and t.stride(-1) == 1
+            return C.c_void_p(t.data_ptr()), (t.stride(0) if t.dim() == 2 else 0)
+
+        rp, rs = out(reward_ring, torch.float32)
+        fp, fs = out(flags_ring, torch.int32)
+        assert rs == fs or rp is None or fp is None, "reward/flags rings must share their slot stride"
+        p = C.c_void_p()
+        with torch.cuda.device(env._dev_index):
+            _lib.check(env._L.nig_plan_create(env._h, self.n_steps, C.c_void_p(action_ring.data_ptr()), ld,
+                                              action_ring.stride(0), R, rp, fp, rs or fs, C.byref(p)))
+        self._p = p
+
+    def launch(self):
+        _lib.check(self.env._L.nig_plan_launch(self._p, self.env._stream()))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.env._L.nig_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

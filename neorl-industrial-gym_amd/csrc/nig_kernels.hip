@@ -33,7 +33,8 @@ struct StepArgs {
     const double *step_noise; const double *reset_noise; int64_t ld_noise;
     float *reward; double *reward64; uint32_t *flags; float *final_obs; int64_t ld_obs;
     // scalars
-    uint64_t env0; uint32_t seed_lo, seed_hi, t;
+    uint64_t env0; uint32_t seed_lo, seed_hi;
+    const uint32_t *t_ptr; uint32_t t_off;   // launch counter t = (t_ptr ? *t_ptr : 0) + t_off (graph replay keeps t on the device)
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
 };
 
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
     {
         const uint64_t gi = p.env0 + (uint64_t)i;
         key.env_lo = (uint32_t)gi; key.env_hi = (uint32_t)(gi >> 32);
-        key.t = p.t; key.seed_lo = p.seed_lo; key.seed_hi = p.seed_hi;
+        key.t = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off; key.seed_lo = p.seed_lo; key.seed_hi = p.seed_hi;
     }
     if constexpr (KS > 0) {
         if constexpr (PARITY) {
@@ -248,6 +249,8 @@ __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long
     }
 }
 
+__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
 __global__ void __launch_bounds__(BLOCK) safety_metrics_kernel(const uint32_t *flags, int32_t *out, int64_t ld_out,
                                                                int64_t B)
 {
@@ -329,6 +332,14 @@ struct nig_handle {
     char *ws;
     bool owns_ws;
     double *scratch;       // reduce scratch [REDUCE_BLOCKS][NIG_T_ROWS] (inside workspace tail)
+    uint32_t *t_dev;       // device copy of t read by graph-replayed step kernels
+};
+
+struct nig_plan {
+    nig_handle *h;
+    int n_steps;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
 };
 
 static unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
@@ -366,6 +377,30 @@ static void launch_step(const StepArgs &a, bool parity, hipStream_t st)
 {
     if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
+}
+
+static StepArgs base_step_args(const nig_handle *h)
+{
+    const nig_layout &L = h->lay;
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = (float *)(h->ws + L.off_state); a.ctr = (uint32_t *)(h->ws + L.off_ctr);
+    a.life_viol = (long long *)(h->ws + L.off_life_viol);
+    a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
+    a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
+    a.ld = L.ld; a.B = h->B;
+    a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
+    a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.hflags = h->flags; a.cmask = h->cmask;
+    return a;
+}
+
+static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, hipStream_t st)
+{
+    switch (h->env) {
+    case NIG_ENV_CHEMICAL_REACTOR: launch_step<ChemicalReactor>(a, parity, st); break;
+    case NIG_ENV_POWER_GRID: launch_step<PowerGrid>(a, parity, st); break;
+    default: launch_step<RobotAssembly>(a, parity, st); break;
+    }
 }
 
 extern "C" {
@@ -410,8 +445,8 @@ int nig_layout_query(int env, int64_t batch, uint32_t flags, nig_layout *out)
         L.off_ep_return = -1;
         L.off_tally = -1;
     }
-    // reduce scratch at the tail
-    off = align_up(off + (int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256);
+    // tail: reduce scratch + the device-resident launch counter used by plans
+    off = align_up(off + (int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256) + 256;
     L.bytes = off;
     *out = L;
     return NIG_OK;
@@ -454,7 +489,8 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
         if (me != hipSuccess) { delete h; return fail(NIG_ERR_HIP, "hipMalloc workspace: %s", hipGetErrorString(me)); }
         h->ws = (char *)p; h->owns_ws = true;
     }
-    h->scratch = (double *)(h->ws + h->lay.bytes - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
+    h->scratch = (double *)(h->ws + h->lay.bytes - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
+    h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - 256);
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
                        (uint32_t *)(h->ws + L.off_ctr), (long long *)(h->ws + L.off_life_viol),
@@ -547,26 +583,74 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act, const double *
         if (ld_noise < h->B) return fail(NIG_ERR_INVALID, "nig_step: ld_noise < batch%s");
     }
     if (final_obs && ld_obs < h->B) return fail(NIG_ERR_INVALID, "nig_step: ld_obs < batch%s");
-    const nig_layout &L = h->lay;
     h->t += 1;
-    StepArgs a;
-    a.state = (float *)(h->ws + L.off_state); a.ctr = (uint32_t *)(h->ws + L.off_ctr);
-    a.life_viol = (long long *)(h->ws + L.off_life_viol);
-    a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
-    a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
-    a.ld = L.ld; a.B = h->B;
+    StepArgs a = base_step_args(h);
     a.actions = actions; a.ld_act = ld_act;
     a.step_noise = step_noise; a.reset_noise = reset_noise; a.ld_noise = ld_noise;
     a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = ld_obs;
-    a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32); a.t = h->t;
-    a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.hflags = h->flags; a.cmask = h->cmask;
-    hipStream_t st = (hipStream_t)stream;
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR: launch_step<ChemicalReactor>(a, parity, st); break;
-    case NIG_ENV_POWER_GRID: launch_step<PowerGrid>(a, parity, st); break;
-    default: launch_step<RobotAssembly>(a, parity, st); break;
-    }
+    a.t_ptr = nullptr; a.t_off = h->t;
+    dispatch_step(h, a, parity, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return NIG_OK;
+}
+
+int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
+                    int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride, nig_plan **out)
+{
+    if (!out) return fail(NIG_ERR_INVALID, "nig_plan_create: out is NULL%s");
+    *out = nullptr;
+    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0 || ld_act < h->B)
+        return fail(NIG_ERR_INVALID, "nig_plan_create: bad argument%s");
+    if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act)
+        return fail(NIG_ERR_INVALID, "nig_plan_create: slot_stride smaller than one [A][ld_act] slot%s");
+    if (out_stride != 0 && out_stride < h->B) return fail(NIG_ERR_INVALID, "nig_plan_create: out_stride < batch%s");
+    nig_plan *p = new (std::nothrow) nig_plan();
+    if (!p) return fail(NIG_ERR_INVALID, "nig_plan_create: out of host memory%s");
+    p->h = h; p->n_steps = n_steps; p->graph = nullptr; p->exec = nullptr;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t cs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete p; return fail(NIG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+    if (e == hipSuccess) {
+        for (int k = 0; k < n_steps; ++k) {
+            StepArgs a = base_step_args(h);
+            const int slot = k % ring_len;
+            a.actions = action_ring + (int64_t)slot * slot_stride; a.ld_act = ld_act;
+            a.reward = reward_out ? reward_out + (int64_t)slot * out_stride : nullptr;
+            a.flags = flags_out ? flags_out + (int64_t)slot * out_stride : nullptr;
+            a.t_ptr = h->t_dev; a.t_off = (uint32_t)(k + 1);
+            dispatch_step(h, a, false, cs);
+        }
+        e = hipStreamEndCapture(cs, &p->graph);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    (void)hipStreamDestroy(cs);
+    if (e != hipSuccess) {
+        if (p->graph) (void)hipGraphDestroy(p->graph);
+        delete p;
+        return fail(NIG_ERR_HIP, "nig_plan_create: graph capture failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return NIG_OK;
+}
+
+int nig_plan_launch(nig_plan *p, void *stream)
+{
+    if (!p) return fail(NIG_ERR_INVALID, "nig_plan_launch: NULL plan%s");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, p->h->t_dev, p->h->t);
+    HIP_TRY(hipGraphLaunch(p->exec, st));
+    p->h->t += (uint32_t)p->n_steps;
+    return NIG_OK;
+}
+
+int nig_plan_destroy(nig_plan *p)
+{
+    if (!p) return NIG_OK;
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    delete p;
     return NIG_OK;
 }
 
