@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--env", default="cr", choices=list(ENVS))
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "rollout"],
+                    help="graph/eager: one step kernel per env.step (step-API); rollout: fused multi-step kernel")
     ap.add_argument("--plan-steps", type=int, default=100, help="steps recorded per hipGraph replay")
     ap.add_argument("--ring", type=int, default=64, help="slots of the pre-filled action ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,15 +99,25 @@ def main():
     for s in range(R):
         env.fill_actions(1000 + s, ring[s])
     env.reset()
-    P = max(1, min(args.plan_steps, args.steps)) if args.mode == "graph" else 1
+    P = max(1, min(args.plan_steps, args.steps)) if args.mode in ("graph", "rollout") else 1
     plan = env.make_plan(P, ring) if args.mode == "graph" else None
+    launches = [0]
 
     def run(n):
+        if args.mode == "rollout":
+            full, rem = divmod(n, P)
+            for _ in range(full):
+                env.rollout(P, ring)
+            if rem:
+                env.rollout(rem, ring)
+            launches[0] += full + (1 if rem else 0)
+            return
         full, rem = (divmod(n, P) if plan is not None else (0, n))
         for _ in range(full):
             plan.launch()
         for k in range(rem):
             env.step_raw(ring[k % R], env.ld, reward=False, flags=False)
+        launches[0] += n
 
     def barrier():
         if world > 1:
@@ -114,6 +125,7 @@ def main():
 
     run(args.warmup)
     torch.cuda.synchronize()
+    launches[0] = 0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -138,8 +150,11 @@ def main():
         steps_total = args.steps * B * world
         value = steps_total / wall
         bytes_step = alg_bytes_per_step(S, A)
-        launch_us = dev_ms * 1e3 / args.steps                   # HIP events over the timed region / launches
-        achieved = bytes_step * B / (launch_us * 1e-6) / 1e9    # GB/s, algorithmic bytes per launch / launch time
+        n_launch = max(launches[0], 1)
+        steps_per_launch = args.steps / n_launch
+        launch_us = dev_ms * 1e3 / n_launch                     # HIP events over the timed region / launches
+        # algorithmic bytes per launch = SURVEY 8(d) per-env-step figure x env-steps one launch processes
+        achieved = bytes_step * B * steps_per_launch / (launch_us * 1e-6) / 1e9    # GB/s
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -153,17 +168,20 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU, step-API (one fused "
-                                   f"step kernel per env.step), {args.mode} launch"
-                                   + (f" ({P} steps per hipGraph replay)" if plan is not None else ""),
+            "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU, "
+                                   + (f"fused rollout kernel ({P} env.step per launch, state in registers)"
+                                      if args.mode == "rollout" else
+                                      f"step-API (one fused step kernel per env.step), {args.mode} launch"
+                                      + (f" ({P} steps per hipGraph replay)" if plan is not None else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "action_ring": R,
                        "autoreset": True, "episode_tally": True,
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_kernel<%s,false>" % {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}[key],
-                         "alg_bytes_per_env_step": bytes_step, "alg_bytes_per_launch": bytes_step * B,
-                         "launch_us": launch_us},
+                         "kernel": ("rollout_kernel<%s>" if args.mode == "rollout" else "step_kernel<%s,false>")
+                                   % {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}[key],
+                         "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": B * steps_per_launch,
+                         "alg_bytes_per_launch": bytes_step * B * steps_per_launch, "launch_us": launch_us},
             "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
                       "critical": int(total[L.T_CRIT]), "return_mean": float(total[L.T_RET_SUM] / max(total[L.T_EPISODES], 1))},
         }

@@ -62,6 +62,8 @@ extern "C" {
 #define NIG_CTR_DONE 0x8000u            /* self.done (base.py:192,197)                       */
 #define NIG_CTR_VIOL_SHIFT 16           /* violation_count of the running episode (base.py:182) */
 #define NIG_MAX_EPISODE_STEPS 21845     /* keeps 3*steps inside 16 bits                      */
+#define NIG_MAX_BATCH (1 << 24)         /* lanes per handle: row offsets stay 32-bit scalars */
+#define NIG_MAX_PITCH (1 << 26)         /* largest caller row pitch (elements)               */
 
 /* rows of the tally array (NIG_F_TALLY), all stored as double, one column per lane */
 enum {
@@ -197,6 +199,25 @@ int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, in
                     int64_t out_stride, nig_plan **out);
 int nig_plan_launch(nig_plan *p, void *stream);
 int nig_plan_destroy(nig_plan *p);
+
+/*
+ * Fused rollout: n_steps consecutive steps of every lane in ONE kernel launch, state held in
+ * registers between steps (fast mode only).  Same per-step semantics, generator keys and
+ * bookkeeping as n_steps calls of nig_step -- the resulting state, counters and tallies are
+ * bit-identical -- but a lane touches memory per step only for its action and for the outputs
+ * requested here:
+ *   action_ring / ld_act / slot_stride / ring_len   as for nig_plan_create
+ *   reward_out, flags_out   optional, row of step k at base + k*out_stride (0 = overwrite)
+ *   obs_out      optional float trajectory: observation returned by step k (the terminal one for
+ *                a lane that finishes) at obs_out + k*obs_step_stride, laid out [S][ld_obs]
+ * Stands in for the step loops of the reference's harnesses: benchmark_environment_steps
+ * (performance_benchmark.py:106-133) and the get_dataset episode loops
+ * (chemical_reactor.py:364-405, power_grid.py:209-237, robot_assembly.py:259-296).
+ */
+int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act,
+                int64_t slot_stride, int32_t ring_len, float *reward_out, uint32_t *flags_out,
+                int64_t out_stride, float *obs_out, int64_t ld_obs, int64_t obs_step_stride,
+                void *stream);
 
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */

@@ -276,6 +276,37 @@ class BatchedIndustrialEnv:
         step k of every replay reads slot k % R.  Optional reward/flags rings [R, B] (or [B])."""
         return StepPlan(self, n_steps, action_ring, reward_ring, flags_ring)
 
+    def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out: Optional[torch.Tensor] = None,
+                flags_out: Optional[torch.Tensor] = None, obs_out: Optional[torch.Tensor] = None):
+        """n_steps fused steps in ONE kernel launch (state stays in registers; fast mode).
+        action_ring: float32 [R, A, ld>=B]; step k reads slot k % R.
+        reward_out float32 / flags_out int32: [n_steps, >=B] (per-step rows) or [B] (overwritten).
+        obs_out: float32 [n_steps, S, >=B] trajectory of returned observations."""
+        assert action_ring.dtype == torch.float32 and action_ring.dim() == 3 and action_ring.stride(2) == 1
+        R, A, ld = action_ring.shape[0], action_ring.shape[1], action_ring.stride(1)
+        assert A == self.action_dim
+
+        def out(t, dtype):
+            if t is None:
+                return None, 0
+            assert t.dtype == dtype and t.stride(-1) == 1
+            if t.dim() == 2:
+                assert t.shape[0] >= n_steps
+                return C.c_void_p(t.data_ptr()), t.stride(0)
+            return C.c_void_p(t.data_ptr()), 0
+
+        rp, rs = out(reward_out, torch.float32)
+        fp, fs = out(flags_out, torch.int32)
+        assert rp is None or fp is None or rs == fs, "reward/flags outputs must share their row stride"
+        op, ldo, so = None, 0, 0
+        if obs_out is not None:
+            assert obs_out.dtype == torch.float32 and obs_out.dim() == 3 and obs_out.stride(2) == 1
+            assert obs_out.shape[0] >= n_steps and obs_out.shape[1] == self.state_dim
+            op, ldo, so = C.c_void_p(obs_out.data_ptr()), obs_out.stride(1), obs_out.stride(0)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_rollout(self._h, int(n_steps), C.c_void_p(action_ring.data_ptr()), ld,
+                                           action_ring.stride(0), R, rp, fp, rs or fs, op, ldo, so, self._stream()))
+
     def fill_actions(self, t: int, out: Optional[torch.Tensor] = None):
         """Synthetic uniform [-1,1) actions of the bench workload for launch counter t -> [A, B]."""
         if out is None:

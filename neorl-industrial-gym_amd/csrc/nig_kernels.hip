@@ -27,11 +27,11 @@ constexpr int REDUCE_BLOCKS = 256;
 struct StepArgs {
     // library-owned
     float *state; uint32_t *ctr; long long *life_viol; double *ep_ret; double *tally;
-    int64_t ld; int64_t B;
+    uint32_t ld; uint32_t B;          // 32-bit on purpose: row offsets k*ld stay in scalar registers
     // caller-owned
-    const float *actions; int64_t ld_act;
-    const double *step_noise; const double *reset_noise; int64_t ld_noise;
-    float *reward; double *reward64; uint32_t *flags; float *final_obs; int64_t ld_obs;
+    const float *actions; uint32_t ld_act;
+    const double *step_noise; const double *reset_noise; uint32_t ld_noise;
+    float *reward; double *reward64; uint32_t *flags; float *final_obs; uint32_t ld_obs;
     // scalars
     uint64_t env0; uint32_t seed_lo, seed_hi;
     const uint32_t *t_ptr; uint32_t t_off;   // launch counter t = (t_ptr ? *t_ptr : 0) + t_off (graph replay keeps t on the device)
@@ -76,46 +76,97 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
     out.terminated = term; out.truncated = trunc;
 }
 
+// Per-lane key of the counter-based generator: (global env index, launch counter t).
+__device__ __forceinline__ RngKey make_key(uint64_t gi, uint32_t t, uint32_t seed_lo, uint32_t seed_hi)
+{
+    RngKey k;
+    k.env_lo = (uint32_t)gi; k.env_hi = (uint32_t)(gi >> 32);
+    k.t = t; k.seed_lo = seed_lo; k.seed_hi = seed_hi;
+    return k;
+}
+
+// Episode bookkeeping of one finished episode (utils.py:120-125), lane-private column of the tally.
+__device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, int step, uint32_t viol_ep, int ncrit)
+{
+    const double len = (double)step;
+    T[NIG_T_EPISODES * ld] += 1.0;
+    T[NIG_T_RET_SUM * ld] += ret;
+    T[NIG_T_RET_SQ * ld] += ret * ret;
+    T[NIG_T_RET_MIN * ld] = fmin(T[NIG_T_RET_MIN * ld], ret);
+    T[NIG_T_RET_MAX * ld] = fmax(T[NIG_T_RET_MAX * ld], ret);
+    T[NIG_T_LEN_SUM * ld] += len;
+    T[NIG_T_LEN_SQ * ld] += len * len;
+    T[NIG_T_VIOL * ld] += (double)viol_ep;
+    T[NIG_T_CRIT * ld] += (double)ncrit;       // a critical step always ends the episode
+    T[NIG_T_SHUTDOWN * ld] += (ncrit > 0) ? 1.0 : 0.0;
+    T[NIG_T_SUCCESS * ld] += (ret > 0.0) ? 1.0 : 0.0;
+}
+
+// One launch = IndustrialEnv.step for every lane.
+//
+// Memory shape: every row pointer is block-uniform (SGPR base) and the lane adds a 32-bit offset,
+// so each access is "global_load_dword v, v_off, s[base]" over one contiguous 1 KiB row segment
+// per block.  All loads (counter, state rows, action rows, injected noise) are issued up front in
+// one batch -- a lane that turns out to be finished just discards them -- so the kernel has one
+// memory round trip before the arithmetic, not two.
+//
+// Auto-reset: lanes that finish are COMPACTED across the 256-lane block through LDS and their
+// initial states are produced by the first ceil(n/64) waves at full lane utilisation (with 18 % of
+// PowerGrid lanes finishing per step every wave would otherwise run the whole reset path for a
+// handful of active lanes).
 template <class Env, bool PARITY>
 __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
+    constexpr int NWAVE = BLOCK / 64;
     using R = typename Env::reward_t;
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= p.B) return;
+    __shared__ unsigned short s_list[BLOCK];
+    __shared__ int s_cnt[NWAVE];
 
-    const uint32_t ctr = p.ctr[i];
-    if (ctr & NIG_CTR_DONE) {                     // base.py:159-160: finished, waiting for reset
-        if (p.flags) p.flags[i] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
-        if (p.reward) p.reward[i] = 0.0f;
-        if (p.reward64) p.reward64[i] = 0.0;
-        return;
-    }
+    const unsigned tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * BLOCK;                  // block-uniform
+    const bool in_range = base + tid < p.B;
+    const uint32_t t_now = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
+
+    // ---- one batch of loads -------------------------------------------------------------
+    const uint32_t *ctr_row = p.ctr + base;
+    const float *st_row = p.state + base;
+    const float *act_row = p.actions + base;
+    uint32_t ctr = NIG_CTR_DONE;
     float s[S], a[A], n[S];
     double nz[KSN];
+    if (in_range) {
+        ctr = ctr_row[tid];
 #pragma unroll
-    for (int k = 0; k < S; ++k) s[k] = p.state[(int64_t)k * p.ld + i];
+        for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld)[tid];
 #pragma unroll
-    for (int k = 0; k < A; ++k) a[k] = p.actions[(int64_t)k * p.ld_act + i];
-
-    RngKey key;
-    {
-        const uint64_t gi = p.env0 + (uint64_t)i;
-        key.env_lo = (uint32_t)gi; key.env_hi = (uint32_t)(gi >> 32);
-        key.t = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off; key.seed_lo = p.seed_lo; key.seed_hi = p.seed_hi;
-    }
-    if constexpr (KS > 0) {
-        if constexpr (PARITY) {
+        for (int k = 0; k < A; ++k) a[k] = (act_row + k * p.ld_act)[tid];
+        if constexpr (PARITY && KS > 0) {
+            const double *nz_row = p.step_noise + base;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) nz[k] = p.step_noise[(int64_t)k * p.ld_noise + i];
-        } else {
-            Env::draw_step(key, nz);
+            for (int k = 0; k < KS; ++k) nz[k] = (nz_row + k * p.ld_noise)[tid];
         }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) a[k] = 0.0f;
+        if constexpr (PARITY && KS > 0) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) nz[k] = 0.0;
+        }
+    }
+    const bool active = in_range && !(ctr & NIG_CTR_DONE);     // base.py:159-160: finished lanes wait for reset
+
+    const RngKey key = make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi);
+    if constexpr (KS > 0) {
+        if constexpr (!PARITY) Env::draw_step(key, nz);
     } else {
         nz[0] = 0.0;
     }
 
+    // ---- IndustrialEnv.step in registers --------------------------------------------------
     const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
     StepResult<Env> res;
     step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
@@ -128,57 +179,178 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
                   ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
                   ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
     uint32_t nctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+    const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
+    const bool need_reset = active && done && autoreset;
 
-    double ret = 0.0;
-    if (p.tally) {                                // utils.py:99  episode_return += reward
-        if constexpr (sizeof(R) == 4) ret = (double)((float)p.ep_ret[i] + res.reward);   // float32 accumulation (CR)
-        else ret = p.ep_ret[i] + (double)res.reward;
-    }
-    if (done) {
-        p.life_viol[i] += (long long)viol_ep;     // base.py:183 total_violations (never reset, base.py:139-141)
-        if (p.tally) {                            // utils.py:120-125 per-episode bookkeeping
-            double *T = p.tally + i;
-            const int64_t ld = p.ld;
-            const double len = (double)step;
-            T[NIG_T_EPISODES * ld] += 1.0;
-            T[NIG_T_RET_SUM * ld] += ret;
-            T[NIG_T_RET_SQ * ld] += ret * ret;
-            T[NIG_T_RET_MIN * ld] = fmin(T[NIG_T_RET_MIN * ld], ret);
-            T[NIG_T_RET_MAX * ld] = fmax(T[NIG_T_RET_MAX * ld], ret);
-            T[NIG_T_LEN_SUM * ld] += len;
-            T[NIG_T_LEN_SQ * ld] += len * len;
-            T[NIG_T_VIOL * ld] += (double)viol_ep;
-            T[NIG_T_CRIT * ld] += (double)res.ncrit;   // a critical step always ends the episode
-            T[NIG_T_SHUTDOWN * ld] += (res.ncrit > 0) ? 1.0 : 0.0;
-            T[NIG_T_SUCCESS * ld] += (ret > 0.0) ? 1.0 : 0.0;
-            ret = 0.0;
+    if (active) {
+        double ret = 0.0;
+        if (p.tally) {                            // utils.py:99  episode_return += reward
+            const double prev = (p.ep_ret + base)[tid];
+            if constexpr (sizeof(R) == 4) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR)
+            else ret = prev + (double)res.reward;
         }
-        if (p.final_obs) {
+        if (done) {
+            (p.life_viol + base)[tid] += (long long)viol_ep;   // base.py:183 total_violations (never reset)
+            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (p.final_obs) {
+                float *fo = p.final_obs + base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) p.final_obs[(int64_t)k * p.ld_obs + i] = n[k];
-        }
-        if (p.hflags & NIG_F_AUTORESET) {         // base.py:133-155 for this lane, same launch
-            double rn[KR];
-            if constexpr (PARITY) {
-#pragma unroll
-                for (int k = 0; k < KR; ++k) rn[k] = p.reset_noise[(int64_t)k * p.ld_noise + i];
-            } else {
-                Env::draw_init(key, rn);
+                for (int k = 0; k < S; ++k) (fo + k * p.ld_obs)[tid] = n[k];
             }
-            Env::init(rn, n);
-            nctr = 0u;
-            fl |= NIG_FLAG_DID_RESET;
-        } else {
-            nctr |= NIG_CTR_DONE;
+            if (autoreset) { nctr = 0u; fl |= NIG_FLAG_DID_RESET; }
+            else nctr |= NIG_CTR_DONE;
         }
+        if (!need_reset) {                        // a resetting lane's state is written by the compacted pass below
+            float *so = p.state + base;
+#pragma unroll
+            for (int k = 0; k < S; ++k) (so + k * p.ld)[tid] = n[k];
+        }
+        (p.ctr + base)[tid] = nctr;
+        if (p.tally) (p.ep_ret + base)[tid] = ret;
+        if (p.reward) (p.reward + base)[tid] = (float)res.reward;
+        if (p.reward64) (p.reward64 + base)[tid] = (double)res.reward;
+        if (p.flags) (p.flags + base)[tid] = fl;
+    } else if (in_range) {
+        if (p.flags) (p.flags + base)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+        if (p.reward) (p.reward + base)[tid] = 0.0f;
+        if (p.reward64) (p.reward64 + base)[tid] = 0.0;
+    }
+
+    // ---- compacted auto-reset: IndustrialEnv.reset (base.py:133-155) for the finished lanes ----
+    if (!autoreset) return;                       // block-uniform
+    const unsigned wave = tid >> 6, lane = tid & 63u;
+    const unsigned long long m = __ballot(need_reset);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    if (need_reset) s_list[wave * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+    __syncthreads();
+    int cnt[NWAVE], total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) { cnt[w] = s_cnt[w]; total += cnt[w]; }
+    for (int j = (int)tid; j < total; j += BLOCK) {
+        int w = 0, r = j;
+#pragma unroll
+        for (int q = 0; q < NWAVE - 1; ++q) { const bool nxt = (w == q) && (r >= cnt[q]); r = nxt ? r - cnt[q] : r; w = nxt ? q + 1 : w; }
+        const unsigned tl = s_list[w * 64 + r];   // block-local index of the lane being reset
+        double rn[KR];
+        if constexpr (PARITY) {
+            const double *rn_row = p.reset_noise + base;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) rn[k] = (rn_row + k * p.ld_noise)[tl];
+        } else {
+            Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_now, p.seed_lo, p.seed_hi), rn);
+        }
+        float r0[S];
+        Env::init(rn, r0);
+        float *so = p.state + base;
+#pragma unroll
+        for (int k = 0; k < S; ++k) (so + k * p.ld)[tl] = r0[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused multi-step rollout: n_steps consecutive IndustrialEnv.step calls per lane in ONE launch.
+// State, counter word and running return live in registers for the whole launch; per step a
+// lane reads only its action (ring slot k % ring_len) and writes only what the caller asked
+// for (reward / flag word / observation of that step).  Lanes are independent, so there is no
+// barrier between steps: waves drift apart and the divergent reset path costs its average,
+// not its maximum.  The arithmetic, the generator keys (t = t_base + k + 1) and the
+// bookkeeping are those of step_kernel: n_steps launches of step_kernel and one launch of
+// this kernel leave bit-identical state, counters and tallies.
+// This is the loop of the reference's own measurement / data-generation harnesses
+// (performance_benchmark.py:106-133; chemical_reactor.py:364-405) with the policy replaced by
+// a pre-filled action ring.
+struct RolloutArgs {
+    StepArgs s;                 // actions = ring base; reward/flags = per-step output bases (optional)
+    int n_steps;
+    int ring_len; uint32_t slot_stride;          // elements between ring slots
+    uint32_t out_stride;                         // elements between per-step reward/flag rows (0: overwrite)
+    float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional [n_steps][S][ld] trajectory
+};
+
+template <class Env>
+__global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
+{
+    constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
+    constexpr int KSN = KS > 0 ? KS : 1;
+    using R = typename Env::reward_t;
+    const StepArgs &p = q.s;
+    const unsigned tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * BLOCK;
+    if (base + tid >= p.B) return;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
+    const uint64_t gi = p.env0 + (uint64_t)(base + tid);
+    const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
+
+    uint32_t ctr = (p.ctr + base)[tid];
+    float s[S], a[A], an[A], n[S];
+    double nz[KSN];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld)[tid];
+    double ret = p.tally ? (p.ep_ret + base)[tid] : 0.0;
+    const float *ring = p.actions + base;
+#pragma unroll
+    for (int k = 0; k < A; ++k) an[k] = (ring + k * p.ld_act)[tid];
+    int slot = 0;
+
+    for (int it = 0; it < q.n_steps; ++it) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) a[k] = an[k];
+        // prefetch the next step's action while this step computes
+        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+        if (it + 1 < q.n_steps) {
+            const float *nx = ring + (size_t)slot * q.slot_stride;
+#pragma unroll
+            for (int k = 0; k < A; ++k) an[k] = (nx + k * p.ld_act)[tid];
+        }
+        const uint32_t orow = (uint32_t)it * q.out_stride;
+        if (ctr & NIG_CTR_DONE) {                 // frozen lane (no auto-reset): base.py:159-160
+            if (p.flags) (p.flags + base + orow)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+            if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
+            continue;
+        }
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+        StepResult<Env> res;
+        step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
+        const int step = step_pre + 1;
+        const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+        const bool done = res.terminated || res.truncated;
+        uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
+                      (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
+                      ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
+                      ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
+        ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+        if (p.tally) {
+            if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
+            else ret = ret + (double)res.reward;
+        }
+        if (q.obs_out) {                          // observation returned by this step (terminal one included)
+            float *oo = q.obs_out + (size_t)it * q.obs_step_stride + base;
+#pragma unroll
+            for (int k = 0; k < S; ++k) (oo + k * q.ld_obs_out)[tid] = n[k];
+        }
+        if (done) {
+            (p.life_viol + base)[tid] += (long long)viol_ep;
+            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (autoreset) {
+                double rn[KR];
+                Env::draw_init(key, rn);
+                Env::init(rn, n);
+                ctr = 0u; fl |= NIG_FLAG_DID_RESET;
+            } else {
+                ctr |= NIG_CTR_DONE;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = n[k];
+        if (p.reward) (p.reward + base + orow)[tid] = (float)res.reward;
+        if (p.flags) (p.flags + base + orow)[tid] = fl;
     }
 #pragma unroll
-    for (int k = 0; k < S; ++k) p.state[(int64_t)k * p.ld + i] = n[k];
-    p.ctr[i] = nctr;
-    if (p.tally) p.ep_ret[i] = ret;
-    if (p.reward) p.reward[i] = (float)res.reward;
-    if (p.reward64) p.reward64[i] = (double)res.reward;
-    if (p.flags) p.flags[i] = fl;
+    for (int k = 0; k < S; ++k) (p.state + base + k * p.ld)[tid] = s[k];
+    (p.ctr + base)[tid] = ctr;
+    if (p.tally) (p.ep_ret + base)[tid] = ret;
 }
 
 struct ResetArgs {
@@ -200,11 +372,7 @@ __global__ void __launch_bounds__(BLOCK) reset_kernel(const ResetArgs p)
 #pragma unroll
         for (int k = 0; k < KR; ++k) rn[k] = p.noise[(int64_t)k * p.ld_noise + i];
     } else {
-        RngKey key;
-        const uint64_t gi = p.env0 + (uint64_t)i;
-        key.env_lo = (uint32_t)gi; key.env_hi = (uint32_t)(gi >> 32);
-        key.t = p.t; key.seed_lo = p.seed_lo; key.seed_hi = p.seed_hi;
-        Env::draw_init(key, rn);
+        Env::draw_init(make_key(p.env0 + (uint64_t)i, p.t, p.seed_lo, p.seed_hi), rn);
     }
     float s[S];
     Env::init(rn, s);
@@ -223,10 +391,7 @@ __global__ void __launch_bounds__(BLOCK) fill_actions_kernel(float *act, int64_t
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
-    RngKey key;
-    const uint64_t gi = env0 + (uint64_t)i;
-    key.env_lo = (uint32_t)gi; key.env_hi = (uint32_t)(gi >> 32);
-    key.t = t; key.seed_lo = seed_lo; key.seed_hi = seed_hi;
+    const RngKey key = make_key(env0 + (uint64_t)i, t, seed_lo, seed_hi);
     double u[Env::A];
     gen_uniforms<Env::A>(key, STREAM_ACTION, u);
 #pragma unroll
@@ -388,7 +553,7 @@ static StepArgs base_step_args(const nig_handle *h)
     a.life_viol = (long long *)(h->ws + L.off_life_viol);
     a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
     a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
-    a.ld = L.ld; a.B = h->B;
+    a.ld = (uint32_t)L.ld; a.B = (uint32_t)h->B;
     a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
     a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.hflags = h->flags; a.cmask = h->cmask;
     return a;
@@ -459,7 +624,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     if (!out) return fail(NIG_ERR_INVALID, "nig_create: out is NULL%s");
     *out = nullptr;
     if (env < 0 || env >= NIG_NUM_ENVS) return fail(NIG_ERR_INVALID, "nig_create: unknown env id%s");
-    if (batch <= 0 || batch > ((int64_t)1 << 40)) return fail(NIG_ERR_INVALID, "nig_create: bad batch%s");
+    if (batch <= 0 || batch > NIG_MAX_BATCH) return fail(NIG_ERR_INVALID, "nig_create: batch outside [1, 2^24]%s");
     if (max_episode_steps < 0 || max_episode_steps > NIG_MAX_EPISODE_STEPS)
         return fail(NIG_ERR_INVALID, "nig_create: max_episode_steps outside [1, 21845]%s");
     if (dt < 0.0 || dt != dt) return fail(NIG_ERR_INVALID, "nig_create: bad dt%s");
@@ -572,7 +737,7 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act, const double *
              int64_t ld_obs, void *stream)
 {
     if (!h) return fail(NIG_ERR_INVALID, "nig_step: NULL handle%s");
-    if (!actions || ld_act < h->B) return fail(NIG_ERR_INVALID, "nig_step: actions NULL or ld_act < batch%s");
+    if (!actions || ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step: actions NULL or ld_act outside [batch, 2^26]%s");
     const nig_env_spec &sp = SPECS[h->env];
     const bool autoreset = (h->flags & NIG_F_AUTORESET) != 0;
     // parity mode = the caller supplies every value the reference's RNG would have drawn
@@ -580,17 +745,50 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act, const double *
     if (parity) {
         if (sp.k_step > 0 && !step_noise) return fail(NIG_ERR_INVALID, "nig_step: parity mode needs step_noise%s");
         if (autoreset && !reset_noise) return fail(NIG_ERR_INVALID, "nig_step: parity mode with auto-reset needs reset_noise%s");
-        if (ld_noise < h->B) return fail(NIG_ERR_INVALID, "nig_step: ld_noise < batch%s");
+        if (ld_noise < h->B || ld_noise > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step: ld_noise outside [batch, 2^26]%s");
     }
-    if (final_obs && ld_obs < h->B) return fail(NIG_ERR_INVALID, "nig_step: ld_obs < batch%s");
+    if (final_obs && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH)) return fail(NIG_ERR_INVALID, "nig_step: ld_obs outside [batch, 2^26]%s");
     h->t += 1;
     StepArgs a = base_step_args(h);
-    a.actions = actions; a.ld_act = ld_act;
-    a.step_noise = step_noise; a.reset_noise = reset_noise; a.ld_noise = ld_noise;
-    a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = ld_obs;
+    a.actions = actions; a.ld_act = (uint32_t)ld_act;
+    a.step_noise = step_noise; a.reset_noise = reset_noise; a.ld_noise = (uint32_t)ld_noise;
+    a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = (uint32_t)ld_obs;
     a.t_ptr = nullptr; a.t_off = h->t;
     dispatch_step(h, a, parity, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return NIG_OK;
+}
+
+int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
+                int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
+{
+    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout: bad argument%s");
+    if (ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout: ld_act outside [batch, 2^26]%s");
+    if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act || slot_stride > 0xffffffffLL)
+        return fail(NIG_ERR_INVALID, "nig_rollout: slot_stride smaller than one [A][ld_act] slot (or >= 2^32)%s");
+    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
+        return fail(NIG_ERR_INVALID, "nig_rollout: out_stride outside {0} U [batch, 2^26]%s");
+    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: n_steps*out_stride >= 2^32%s");
+    if (obs_out && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH || obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs))
+        return fail(NIG_ERR_INVALID, "nig_rollout: bad observation trajectory pitch%s");
+    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: launch counter would wrap%s");
+    RolloutArgs q;
+    memset(&q, 0, sizeof q);
+    q.s = base_step_args(h);
+    q.s.actions = action_ring; q.s.ld_act = (uint32_t)ld_act;
+    q.s.reward = reward_out; q.s.flags = flags_out;
+    q.s.t_ptr = nullptr; q.s.t_off = h->t;
+    q.n_steps = n_steps; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
+    q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride;
+    hipStream_t st = (hipStream_t)stream;
+    switch (h->env) {
+    case NIG_ENV_CHEMICAL_REACTOR: hipLaunchKernelGGL((rollout_kernel<ChemicalReactor>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    case NIG_ENV_POWER_GRID: hipLaunchKernelGGL((rollout_kernel<PowerGrid>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    default: hipLaunchKernelGGL((rollout_kernel<RobotAssembly>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    }
+    HIP_TRY(hipGetLastError());
+    h->t += (uint32_t)n_steps;
     return NIG_OK;
 }
 
@@ -599,7 +797,7 @@ int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, in
 {
     if (!out) return fail(NIG_ERR_INVALID, "nig_plan_create: out is NULL%s");
     *out = nullptr;
-    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0 || ld_act < h->B)
+    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0 || ld_act < h->B || ld_act > NIG_MAX_PITCH)
         return fail(NIG_ERR_INVALID, "nig_plan_create: bad argument%s");
     if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act)
         return fail(NIG_ERR_INVALID, "nig_plan_create: slot_stride smaller than one [A][ld_act] slot%s");
@@ -616,7 +814,7 @@ int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, in
         for (int k = 0; k < n_steps; ++k) {
             StepArgs a = base_step_args(h);
             const int slot = k % ring_len;
-            a.actions = action_ring + (int64_t)slot * slot_stride; a.ld_act = ld_act;
+            a.actions = action_ring + (int64_t)slot * slot_stride; a.ld_act = (uint32_t)ld_act;
             a.reward = reward_out ? reward_out + (int64_t)slot * out_stride : nullptr;
             a.flags = flags_out ? flags_out + (int64_t)slot * out_stride : nullptr;
             a.t_ptr = h->t_dev; a.t_off = (uint32_t)(k + 1);
