@@ -3,12 +3,21 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE).
-A "step" = one IndustrialEnv.step() of every lane of the batch (one launch of the fused step
-kernel).  Workload at N=1 = BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs,
-uniform random float32 actions from a pre-filled on-device ring, process noise and auto-reset
-drawn in-kernel from the counter-based generator (synthetic data).  Every rank
-runs the same per-GPU batch (weak scaling); lanes are keyed by global index; the only
-collective is the all-gather of the 11-double episode tally after the timed region.
+A "step" = one IndustrialEnv.step() of every lane of the batch.  Workload at N=1 =
+BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs, uniform random float32
+actions from a pre-filled on-device ring, process noise and auto-reset drawn in-kernel from the
+counter-based generator (synthetic data).  Every rank runs the same per-GPU batch
+(weak scaling); lanes are keyed by global index; the only collective is the all-gather of the
+11-double episode tally after the timed region.
+
+Modes (same arithmetic, bit-identical results -- tests/test_gpu_parity.py):
+  rollout (default)  fused rollout kernel: --plan-steps env.step per launch, state in registers;
+                     EVERY step's return values are still materialised in HBM (observation
+                     trajectory, reward, flag word), i.e. the information of the step API.
+  graph / eager      step API: one step-kernel launch per env.step (state round-trips HBM),
+                     replayed from a hipGraph / launched one by one.
+The headline `value` is the selected mode; the default run also times the step API for a
+shorter stretch and reports it under "step_api".
 
 One JSON line on rank 0:  metric/value/unit/... + "roofline" + "cpu_baseline" (+ "parity").
 """
@@ -31,6 +40,13 @@ def alg_bytes_per_step(S, A):
     return 8 * S + 4 * A + 16
 
 
+def alg_bytes_rollout(S, A, outputs):
+    """SURVEY.md 8(d), fused-rollout mode (reported separately from the step-API figure): per
+    env-step the action is read (4A) and the requested return values are written: observation
+    4S, reward 4, flag word 4.  State/counters move once per LAUNCH (amortised, not counted)."""
+    return 4 * A + {"full": 4 * S + 8, "min": 8, "none": 0}[outputs]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -38,10 +54,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--env", default="cr", choices=list(ENVS))
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "rollout"],
+    ap.add_argument("--mode", default="rollout", choices=["graph", "eager", "rollout"],
                     help="graph/eager: one step kernel per env.step (step-API); rollout: fused multi-step kernel")
     ap.add_argument("--plan-steps", type=int, default=100, help="steps recorded per hipGraph replay")
     ap.add_argument("--ring", type=int, default=64, help="slots of the pre-filled action ring")
+    ap.add_argument("--outputs", default="full", choices=["full", "min", "none"],
+                    help="rollout mode: full = obs trajectory + reward + flags per step; min = reward + flags; none")
+    ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
+    ap.add_argument("--calibrate", action="store_true", help="also run known-size dword copies (PMC calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
@@ -75,21 +95,24 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity:
         from oracle import oracle as O
-        Tp = 32
+        L0 = ni._lib
+        Tp = 256
         penv = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=0, autoreset=True)
+        pring = torch.empty(Tp, A, penv.ld, dtype=torch.float32, device=device)
+        for t in range(Tp):
+            penv.fill_actions(t + 1, pring[t])         # slot k = the generator's action stream at t = k + 1
+        pfl = torch.zeros(Tp, penv.ld, dtype=torch.int32, device=device)
         penv.reset()
-        viol = torch.zeros((), dtype=torch.int64, device=device)
-        crit = torch.zeros((), dtype=torch.int64, device=device)
-        pact = torch.empty(A, penv.ld, dtype=torch.float32, device=device)
-        for t in range(1, Tp + 1):
-            penv.fill_actions(t, pact)
-            _, _, _, _, info = penv.step(pact[:, :B], layout="soa")
-            viol += info.violation_count.sum()
-            crit += info.critical_violations.sum()
+        penv.rollout(Tp, pring, None, pfl)
+        viol = ((pfl[:, :B] >> L0.FLAG_NVIOL_SHIFT) & 3).sum()
+        crit = ((pfl[:, :B] >> L0.FLAG_NCRIT_SHIFT) & 3).sum()
+        nres = ((pfl[:, :B] & L0.FLAG_DID_RESET) != 0).sum()
         st, sc, tot, _ = O.rollout(key, B, Tp, seed=seed, flavor=O.MATH_POLY, nthreads=min(os.cpu_count() or 1, 32))
         same = bool(np.array_equal(penv.get_state().cpu().numpy().view(np.uint32), st.view(np.uint32)))
         parity = {"lanes": B, "steps": Tp, "violations_gpu": int(viol.item()), "violations_cpu": int(tot.violations),
-                  "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical), "state_bits_equal": same}
+                  "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical),
+                  "episodes_gpu": int(nres.item()), "episodes_cpu": int(tot.episodes), "state_bits_equal": same}
+        del pring, pfl
         penv.close()
         del penv
 
@@ -100,24 +123,39 @@ def main():
         env.fill_actions(1000 + s, ring[s])
     env.reset()
     P = max(1, min(args.plan_steps, args.steps)) if args.mode in ("graph", "rollout") else 1
-    plan = env.make_plan(P, ring) if args.mode == "graph" else None
+    plan = None
     launches = [0]
+    traj = rew_t = fl_t = None
+    if args.mode == "rollout" and args.outputs != "none":
+        rew_t = torch.empty(P, env.ld, dtype=torch.float32, device=device)
+        fl_t = torch.empty(P, env.ld, dtype=torch.int32, device=device)
+        if args.outputs == "full":
+            traj = torch.empty(P, S, env.ld, dtype=torch.float32, device=device)
+
+    def run_rollout(n):
+        full, rem = divmod(n, P)
+        for _ in range(full):
+            env.rollout(P, ring, rew_t, fl_t, traj)
+        if rem:
+            env.rollout(rem, ring, rew_t, fl_t, traj)
+        launches[0] += full + (1 if rem else 0)
+
+    def run_step_api(n, use_plan):
+        full, rem = (divmod(n, P) if use_plan is not None else (0, n))
+        for _ in range(full):
+            use_plan.launch()
+        for k in range(rem):
+            env.step_raw(ring[k % R], env.ld, reward=True, flags=True)
+        launches[0] += n
+
+    if args.mode == "graph":
+        plan = env.make_plan(P, ring, env.reward, env.flags)
 
     def run(n):
         if args.mode == "rollout":
-            full, rem = divmod(n, P)
-            for _ in range(full):
-                env.rollout(P, ring)
-            if rem:
-                env.rollout(rem, ring)
-            launches[0] += full + (1 if rem else 0)
-            return
-        full, rem = (divmod(n, P) if plan is not None else (0, n))
-        for _ in range(full):
-            plan.launch()
-        for k in range(rem):
-            env.step_raw(ring[k % R], env.ld, reward=False, flags=False)
-        launches[0] += n
+            run_rollout(n)
+        else:
+            run_step_api(n, plan)
 
     def barrier():
         if world > 1:
@@ -141,6 +179,31 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tmax[0].item()), float(tmax[1].item())
 
+    # ---- secondary measurement: the step API (one kernel launch per env.step, hipGraph replay)
+    step_api = None
+    if args.mode == "rollout" and not args.no_step_api:
+        K2 = max(P, min(args.steps, 4000) // P * P)
+        plan2 = env.make_plan(P, ring, env.reward, env.flags)
+        run_step_api(P, plan2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier(); torch.cuda.synchronize()
+        w0 = time.perf_counter(); e0.record()
+        run_step_api(K2, plan2)
+        e1.record(); torch.cuda.synchronize(); barrier()
+        w2 = time.perf_counter() - w0
+        tm2 = torch.tensor([w2, e0.elapsed_time(e1)], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+        step_api = (K2, float(tm2[0].item()), float(tm2[1].item()))
+        plan2.close()
+
+    if args.calibrate:   # known-size dword-per-lane copies for the PMC byte calibration (profiles/)
+        cal = torch.empty(S, env.ld, dtype=torch.float32, device=device)
+        for _ in range(20):
+            ni._lib.check(env._L.nig_get_state(env._h, cal.data_ptr(), env.ld, None, env._stream()))
+        torch.cuda.synchronize()
+
     # ---- the path's one exchange: final tally reduction (after the timed region)
     from neorl_industrial_gym_amd.parallel import all_reduce_partial
     total = all_reduce_partial(env.reduce_tally()).cpu().numpy()
@@ -149,8 +212,9 @@ def main():
     if rank == 0:
         steps_total = args.steps * B * world
         value = steps_total / wall
-        bytes_step = alg_bytes_per_step(S, A)
-        n_launch = max(launches[0], 1)
+        rollout_mode = args.mode == "rollout"
+        bytes_step = alg_bytes_rollout(S, A, args.outputs) if rollout_mode else alg_bytes_per_step(S, A)
+        n_launch = max(launches[0], 1) if not rollout_mode else (args.steps // P + (1 if args.steps % P else 0))
         steps_per_launch = args.steps / n_launch
         launch_us = dev_ms * 1e3 / n_launch                     # HIP events over the timed region / launches
         # algorithmic bytes per launch = SURVEY 8(d) per-env-step figure x env-steps one launch processes
@@ -159,7 +223,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{key}_{B}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"{key}_{B}_{args.mode}_{args.outputs if rollout_mode else 'step'}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -169,7 +233,8 @@ def main():
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU, "
-                                   + (f"fused rollout kernel ({P} env.step per launch, state in registers)"
+                                   + (f"fused rollout kernel ({P} env.step per launch, state in registers, "
+                                      f"per-step outputs: {args.outputs})"
                                       if args.mode == "rollout" else
                                       f"step-API (one fused step kernel per env.step), {args.mode} launch"
                                       + (f" ({P} steps per hipGraph replay)" if plan is not None else "")),
@@ -181,10 +246,20 @@ def main():
                          "kernel": ("rollout_kernel<%s>" if args.mode == "rollout" else "step_kernel<%s,false>")
                                    % {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}[key],
                          "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": B * steps_per_launch,
-                         "alg_bytes_per_launch": bytes_step * B * steps_per_launch, "launch_us": launch_us},
+                         "alg_bytes_per_launch": bytes_step * B * steps_per_launch, "launch_us": launch_us,
+                         "bytes_model": ("fused-rollout figure (SURVEY 8d): action read + requested per-step outputs"
+                                         if rollout_mode else "step-API figure (SURVEY 8d): 8S+4A+16")},
             "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
                       "critical": int(total[L.T_CRIT]), "return_mean": float(total[L.T_RET_SUM] / max(total[L.T_EPISODES], 1))},
         }
+        if step_api is not None:
+            K2, w2, d2 = step_api
+            b2 = alg_bytes_per_step(S, A)
+            out["step_api"] = {"value": K2 * B * world / w2, "unit": "env-steps/s", "steps": K2,
+                               "launch_us": d2 * 1e3 / K2, "alg_bytes_per_env_step": b2,
+                               "achieved_GBps": b2 * B / (d2 * 1e-3 / K2) / 1e9,
+                               "frac_of_hbm_peak": b2 * B / (d2 * 1e-3 / K2) / 1e9 / HBM_PEAK_GBS,
+                               "note": "one step_kernel launch per env.step, hipGraph replay"}
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csvs into per-launch HBM bytes.
+
+Calibration (MI355X_MICROARCH.md "HBM"): on gfx950 FETCH_SIZE is exact only for some access
+widths (it reads 1/2 for 16 B/lane streams) and "other access widths are uncalibrated", so the
+byte scale for THIS code's dword-per-lane row accesses is taken from copy_rows_kernel dispatches
+of known size in the same run (bench.py --calibrate): scale = known bytes / counter value.
+Writes gpurun_out/pmc_<tag>/traffic_<tag>.json; merge the entry into profiles/traffic.json.
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def load(path):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    args = sys.argv[3:]
+    env = args[args.index("--env") + 1] if "--env" in args else "cr"
+    S = {"cr": 12, "pg": 32, "ra": 24}[env]
+    B = int(args[args.index("--batch") + 1]) if "--batch" in args else {"cr": 65536, "pg": 262144, "ra": 262144}[env]
+    ld = (B + 63) // 64 * 64
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = load(os.path.join(out, f"{tag}_{ctr}.csv"))
+        cal = [v for k, vs in per.items() if "copy_rows_kernel" in k for v in vs]
+        known = S * B * 4.0                       # bytes read (and written) by one copy_rows dispatch
+        cal = sorted(cal)[len(cal) // 2] if cal else None
+        scale = (known / cal) if cal else None    # bytes per counter unit for dword-per-lane rows
+        for k, vs in per.items():
+            if re.search(r"rollout_kernel|step_kernel", k):
+                vs = sorted(vs)
+                med = vs[len(vs) // 2]
+                res.setdefault(k, {})[ctr] = {"median_counter": med, "calibrated_scale_bytes_per_unit": scale,
+                                              "bytes_per_launch": med * scale if scale else None,
+                                              "copy_rows_counter": cal, "copy_rows_known_bytes": known, "n": len(vs)}
+    summary = {}
+    for k, d in res.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d and d["FETCH_SIZE"]["bytes_per_launch"] is not None:
+            summary[k] = {"hbm_bytes_per_launch": d["FETCH_SIZE"]["bytes_per_launch"] + d["WRITE_SIZE"]["bytes_per_launch"],
+                          "detail": d}
+    path = os.path.join(out, f"traffic_{tag}.json")
+    json.dump(summary, open(path, "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
