@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="slots of the pre-filled action ring")
     ap.add_argument("--outputs", default="full", choices=["full", "min", "none"],
                     help="rollout mode: full = obs trajectory + reward + flags per step; min = reward + flags; none")
+    ap.add_argument("--traj", default="aos", choices=["aos", "soa"], help="observation trajectory layout: [T,B,S] or [T,S,ld]")
     ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
     ap.add_argument("--calibrate", action="store_true", help="also run known-size dword copies (PMC calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,11 +78,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # NIG_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend (a 1-GPU box cannot host two
+    # RCCL ranks); used only to rehearse the N>1 control flow, never for a reported number.
+    rehearse = os.environ.get("NIG_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+    comm_dev = torch.device("cpu") if rehearse else device
 
     import neorl_industrial_gym_amd as ni
 
@@ -103,7 +112,8 @@ def main():
             penv.fill_actions(t + 1, pring[t])         # slot k = the generator's action stream at t = k + 1
         pfl = torch.zeros(Tp, penv.ld, dtype=torch.int32, device=device)
         penv.reset()
-        penv.rollout(Tp, pring, None, pfl)
+        prw = torch.zeros(Tp, penv.ld, dtype=torch.float32, device=device)
+        penv.rollout(Tp, pring, prw, pfl)
         viol = ((pfl[:, :B] >> L0.FLAG_NVIOL_SHIFT) & 3).sum()
         crit = ((pfl[:, :B] >> L0.FLAG_NCRIT_SHIFT) & 3).sum()
         nres = ((pfl[:, :B] & L0.FLAG_DID_RESET) != 0).sum()
@@ -112,7 +122,7 @@ def main():
         parity = {"lanes": B, "steps": Tp, "violations_gpu": int(viol.item()), "violations_cpu": int(tot.violations),
                   "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical),
                   "episodes_gpu": int(nres.item()), "episodes_cpu": int(tot.episodes), "state_bits_equal": same}
-        del pring, pfl
+        del pring, pfl, prw
         penv.close()
         del penv
 
@@ -130,7 +140,8 @@ def main():
         rew_t = torch.empty(P, env.ld, dtype=torch.float32, device=device)
         fl_t = torch.empty(P, env.ld, dtype=torch.int32, device=device)
         if args.outputs == "full":
-            traj = torch.empty(P, S, env.ld, dtype=torch.float32, device=device)
+            traj = (torch.empty(P, B, S, dtype=torch.float32, device=device) if args.traj == "aos"   # row-major [T,B,S]
+                    else torch.empty(P, S, env.ld, dtype=torch.float32, device=device))
 
     def run_rollout(n):
         full, rem = divmod(n, P)
@@ -174,7 +185,7 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tmax[0].item()), float(tmax[1].item())
@@ -192,7 +203,7 @@ def main():
         run_step_api(K2, plan2)
         e1.record(); torch.cuda.synchronize(); barrier()
         w2 = time.perf_counter() - w0
-        tm2 = torch.tensor([w2, e0.elapsed_time(e1)], dtype=torch.float64, device=device)
+        tm2 = torch.tensor([w2, e0.elapsed_time(e1)], dtype=torch.float64, device=comm_dev)
         if world > 1:
             dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
         step_api = (K2, float(tm2[0].item()), float(tm2[1].item()))
@@ -206,7 +217,7 @@ def main():
 
     # ---- the path's one exchange: final tally reduction (after the timed region)
     from neorl_industrial_gym_amd.parallel import all_reduce_partial
-    total = all_reduce_partial(env.reduce_tally()).cpu().numpy()
+    total = all_reduce_partial(env.reduce_tally().to(comm_dev)).cpu().numpy()
     L = ni._lib
 
     if rank == 0:

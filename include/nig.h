@@ -207,9 +207,12 @@ int nig_plan_destroy(nig_plan *p);
  * bit-identical -- but a lane touches memory per step only for its action and for the outputs
  * requested here:
  *   action_ring / ld_act / slot_stride / ring_len   as for nig_plan_create
- *   reward_out, flags_out   optional, row of step k at base + k*out_stride (0 = overwrite)
- *   obs_out      optional float trajectory: observation returned by step k (the terminal one for
- *                a lane that finishes) at obs_out + k*obs_step_stride, laid out [S][ld_obs]
+ *   reward_out, flags_out   optional (both or neither), row of step k at base + k*out_stride
+ *                (0 = overwrite)
+ *   obs_out      optional (needs reward_out/flags_out) float trajectory: observation returned by step k (the terminal one for
+ *                a lane that finishes) at obs_out + k*obs_step_stride, laid out [S][ld_obs], or
+ *                -- with ld_obs == 0 -- row-major [B][S] (16-byte aligned; the D4RL
+ *                observations[N,S] layout, written with 16-byte stores)
  * Stands in for the step loops of the reference's harnesses: benchmark_environment_steps
  * (performance_benchmark.py:106-133) and the get_dataset episode loops
  * (chemical_reactor.py:364-405, power_grid.py:209-237, robot_assembly.py:259-296).

@@ -281,7 +281,8 @@ class BatchedIndustrialEnv:
         """n_steps fused steps in ONE kernel launch (state stays in registers; fast mode).
         action_ring: float32 [R, A, ld>=B]; step k reads slot k % R.
         reward_out float32 / flags_out int32: [n_steps, >=B] (per-step rows) or [B] (overwritten).
-        obs_out: float32 [n_steps, S, >=B] trajectory of returned observations."""
+        obs_out: float32 trajectory of returned observations, [n_steps, S, >=B] (SoA rows) or
+        contiguous [n_steps, B, S] (row-major transitions, D4RL layout; fastest to write)."""
         assert action_ring.dtype == torch.float32 and action_ring.dim() == 3 and action_ring.stride(2) == 1
         R, A, ld = action_ring.shape[0], action_ring.shape[1], action_ring.stride(1)
         assert A == self.action_dim
@@ -297,12 +298,19 @@ class BatchedIndustrialEnv:
 
         rp, rs = out(reward_out, torch.float32)
         fp, fs = out(flags_out, torch.int32)
-        assert rp is None or fp is None or rs == fs, "reward/flags outputs must share their row stride"
+        assert (rp is None) == (fp is None), "reward_out and flags_out go together (both or neither)"
+        assert rp is None or rs == fs, "reward/flags outputs must share their row stride"
+        assert obs_out is None or rp is not None, "an observation trajectory needs reward_out and flags_out too"
         op, ldo, so = None, 0, 0
         if obs_out is not None:
             assert obs_out.dtype == torch.float32 and obs_out.dim() == 3 and obs_out.stride(2) == 1
-            assert obs_out.shape[0] >= n_steps and obs_out.shape[1] == self.state_dim
-            op, ldo, so = C.c_void_p(obs_out.data_ptr()), obs_out.stride(1), obs_out.stride(0)
+            assert obs_out.shape[0] >= n_steps
+            if obs_out.shape[1:] == (self.batch, self.state_dim) and obs_out.stride(1) == self.state_dim \
+                    and self.batch != self.state_dim:
+                op, ldo, so = C.c_void_p(obs_out.data_ptr()), 0, obs_out.stride(0)          # row-major [T,B,S]
+            else:
+                assert obs_out.shape[1] == self.state_dim and obs_out.shape[2] >= self.batch
+                op, ldo, so = C.c_void_p(obs_out.data_ptr()), obs_out.stride(1), obs_out.stride(0)
         with torch.cuda.device(self._dev_index):
             _lib.check(self._L.nig_rollout(self._h, int(n_steps), C.c_void_p(action_ring.data_ptr()), ld,
                                            action_ring.stride(0), R, rp, fp, rs or fs, op, ldo, so, self._stream()))

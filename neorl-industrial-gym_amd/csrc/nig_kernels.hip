@@ -86,21 +86,69 @@ __device__ __forceinline__ RngKey make_key(uint64_t gi, uint32_t t, uint32_t see
 }
 
 // Episode bookkeeping of one finished episode (utils.py:120-125), lane-private column of the tally.
+// All 11 rows are loaded before any is stored: one memory round trip instead of eleven dependent ones.
 __device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, int step, uint32_t viol_ep, int ncrit)
 {
+    double v[NIG_T_ROWS];
+#pragma unroll
+    for (int r = 0; r < NIG_T_ROWS; ++r) v[r] = T[(size_t)r * ld];
     const double len = (double)step;
-    T[NIG_T_EPISODES * ld] += 1.0;
-    T[NIG_T_RET_SUM * ld] += ret;
-    T[NIG_T_RET_SQ * ld] += ret * ret;
-    T[NIG_T_RET_MIN * ld] = fmin(T[NIG_T_RET_MIN * ld], ret);
-    T[NIG_T_RET_MAX * ld] = fmax(T[NIG_T_RET_MAX * ld], ret);
-    T[NIG_T_LEN_SUM * ld] += len;
-    T[NIG_T_LEN_SQ * ld] += len * len;
-    T[NIG_T_VIOL * ld] += (double)viol_ep;
-    T[NIG_T_CRIT * ld] += (double)ncrit;       // a critical step always ends the episode
-    T[NIG_T_SHUTDOWN * ld] += (ncrit > 0) ? 1.0 : 0.0;
-    T[NIG_T_SUCCESS * ld] += (ret > 0.0) ? 1.0 : 0.0;
+    v[NIG_T_EPISODES] += 1.0;
+    v[NIG_T_RET_SUM] += ret;
+    v[NIG_T_RET_SQ] += ret * ret;
+    v[NIG_T_RET_MIN] = fmin(v[NIG_T_RET_MIN], ret);
+    v[NIG_T_RET_MAX] = fmax(v[NIG_T_RET_MAX], ret);
+    v[NIG_T_LEN_SUM] += len;
+    v[NIG_T_LEN_SQ] += len * len;
+    v[NIG_T_VIOL] += (double)viol_ep;
+    v[NIG_T_CRIT] += (double)ncrit;            // a critical step always ends the episode
+    v[NIG_T_SHUTDOWN] += (ncrit > 0) ? 1.0 : 0.0;
+    v[NIG_T_SUCCESS] += (ret > 0.0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < NIG_T_ROWS; ++r) T[(size_t)r * ld] = v[r];
 }
+
+// Register-resident partial tally of one lane for the duration of a fused rollout.
+struct LaneTally {
+    double ret_sum, ret_sq, ret_min, ret_max, len_sq;
+    int episodes, len_sum, viol, crit, shutdown, success;
+    long long life;
+    __device__ __forceinline__ void clear()
+    {
+        ret_sum = 0.0; ret_sq = 0.0; ret_min = __builtin_inf(); ret_max = -__builtin_inf(); len_sq = 0.0;
+        episodes = 0; len_sum = 0; viol = 0; crit = 0; shutdown = 0; success = 0; life = 0;
+    }
+    __device__ __forceinline__ void episode(double ret, int step, uint32_t viol_ep, int ncrit)
+    {
+        const double len = (double)step;
+        episodes += 1; ret_sum += ret; ret_sq += ret * ret;
+        ret_min = fmin(ret_min, ret); ret_max = fmax(ret_max, ret);
+        len_sum += step; len_sq += len * len;
+        viol += (int)viol_ep; crit += ncrit; shutdown += (ncrit > 0) ? 1 : 0; success += (ret > 0.0) ? 1 : 0;
+    }
+    // merge into the lane's column of the global tally (same fp64 operation order per row as
+    // flush_tally would have produced when at most one episode finished; sums of several
+    // episodes are added as one partial -- integer rows exact, fp rows within 1 ulp of fp64)
+    __device__ __forceinline__ void merge(double *T, uint32_t ld) const
+    {
+        double v[NIG_T_ROWS];
+#pragma unroll
+        for (int r = 0; r < NIG_T_ROWS; ++r) v[r] = T[(size_t)r * ld];
+        v[NIG_T_EPISODES] += (double)episodes;
+        v[NIG_T_RET_SUM] += ret_sum;
+        v[NIG_T_RET_SQ] += ret_sq;
+        v[NIG_T_RET_MIN] = fmin(v[NIG_T_RET_MIN], ret_min);
+        v[NIG_T_RET_MAX] = fmax(v[NIG_T_RET_MAX], ret_max);
+        v[NIG_T_LEN_SUM] += (double)len_sum;
+        v[NIG_T_LEN_SQ] += len_sq;
+        v[NIG_T_VIOL] += (double)viol;
+        v[NIG_T_CRIT] += (double)crit;
+        v[NIG_T_SHUTDOWN] += (double)shutdown;
+        v[NIG_T_SUCCESS] += (double)success;
+#pragma unroll
+        for (int r = 0; r < NIG_T_ROWS; ++r) T[(size_t)r * ld] = v[r];
+    }
+};
 
 // One launch = IndustrialEnv.step for every lane.
 //
@@ -264,10 +312,15 @@ struct RolloutArgs {
     int n_steps;
     int ring_len; uint32_t slot_stride;          // elements between ring slots
     uint32_t out_stride;                         // elements between per-step reward/flag rows (0: overwrite)
-    float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional [n_steps][S][ld] trajectory
+    float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional trajectory, [n_steps][S][ld] ...
+    int obs_aos;                                                     // ... or row-major transitions [n_steps][B][S]
 };
 
-template <class Env>
+// OUT: 0 = no per-step outputs, 1 = reward + flag word, 2 = + observation rows [S][ld],
+//      3 = + observation row-major [B][S].  Compile-time so that the number of stores per
+// iteration is static and the wait for the prefetched action is a counted vmcnt(N), not a
+// full drain of the iteration's stores.
+template <class Env, int OUT>
 __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
@@ -280,34 +333,41 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
     const uint64_t gi = p.env0 + (uint64_t)(base + tid);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
+    const bool tally = p.tally != nullptr;
 
     uint32_t ctr = (p.ctr + base)[tid];
-    float s[S], a[A], an[A], n[S];
+    float s[S], a[A], n[S];
     double nz[KSN];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld)[tid];
-    double ret = p.tally ? (p.ep_ret + base)[tid] : 0.0;
+    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    LaneTally lt;
+    lt.clear();
+    // Actions are prefetched TWO steps ahead into two ping-pong register sets (the loop is unrolled
+    // by two so no register copy sits between load and use).  vmcnt retires in issue order, so the
+    // wait for a prefetched action also waits for every store issued before it; at distance 2 those
+    // are the stores of two steps ago, acknowledged long before (a distance-1 prefetch stalled ~20 %
+    // of the wave's cycles on the previous step's store acknowledgements).
     const float *ring = p.actions + base;
+    float bufA[A], bufB[A];
+    int slot = (q.ring_len > 1) ? 1 : 0;
 #pragma unroll
-    for (int k = 0; k < A; ++k) an[k] = (ring + k * p.ld_act)[tid];
-    int slot = 0;
+    for (int k = 0; k < A; ++k) bufA[k] = (ring + k * p.ld_act)[tid];
+    {
+        const float *nx = ring + (size_t)slot * q.slot_stride;
+#pragma unroll
+        for (int k = 0; k < A; ++k) bufB[k] = (nx + k * p.ld_act)[tid];
+    }
+    // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
+    // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
+    // waits sized for the first one.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
-    for (int it = 0; it < q.n_steps; ++it) {
+    auto one_step = [&](float (&abuf)[A], const int it) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = an[k];
-        // prefetch the next step's action while this step computes
-        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-        if (it + 1 < q.n_steps) {
-            const float *nx = ring + (size_t)slot * q.slot_stride;
-#pragma unroll
-            for (int k = 0; k < A; ++k) an[k] = (nx + k * p.ld_act)[tid];
-        }
+        for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const uint32_t orow = (uint32_t)it * q.out_stride;
-        if (ctr & NIG_CTR_DONE) {                 // frozen lane (no auto-reset): base.py:159-160
-            if (p.flags) (p.flags + base + orow)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
-            if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
-            continue;
-        }
+        const bool frozen = (ctr & NIG_CTR_DONE) != 0;             // no auto-reset: base.py:159-160
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
         if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
@@ -315,42 +375,82 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
-        const bool done = res.terminated || res.truncated;
+        const bool done = (res.terminated || res.truncated) && !frozen;
         uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
                       (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
                       ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
                       ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
-        ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
-        if (p.tally) {
-            if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
-            else ret = ret + (double)res.reward;
+        float rew = (float)res.reward;
+        if (frozen) {                              // untouched lane: discard the speculative step
+            fl = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+            rew = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) n[k] = s[k];
+        } else {
+            ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+            if (tally) {
+                if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
+                else ret = ret + (double)res.reward;
+            }
         }
-        if (q.obs_out) {                          // observation returned by this step (terminal one included)
+        // Refill this buffer with the action of step it+2, issued BEFORE this step's stores: the
+        // registers of `a` are dead by now (the load lands in place, no rotation of register sets),
+        // and the in-order vmcnt wait at the top of step it+2 then only needs the stores of step
+        // it-1 and older to have been acknowledged -- two full steps of slack.
+        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+        {
+            const float *nx = ring + (size_t)slot * q.slot_stride;
+#pragma unroll
+            for (int k = 0; k < A; ++k) abuf[k] = (nx + k * p.ld_act)[tid];
+        }
+        if constexpr (OUT == 3) {
+            // row-major transitions [step][lane][S] (the D4RL "observations[N,S]" layout): each lane
+            // owns 4*S contiguous bytes, written as S/4 16-byte stores (12 dword stores -> 3 for CR)
+            float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) +
+                         (size_t)(base + tid) * (S / 4);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]);
+        } else if constexpr (OUT == 2) {
             float *oo = q.obs_out + (size_t)it * q.obs_step_stride + base;
 #pragma unroll
             for (int k = 0; k < S; ++k) (oo + k * q.ld_obs_out)[tid] = n[k];
         }
+        if constexpr (OUT >= 1) {
+            (p.reward + base + orow)[tid] = rew;
+            (p.flags + base + orow)[tid] = fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
+        }
         if (done) {
-            (p.life_viol + base)[tid] += (long long)viol_ep;
-            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            lt.life += (long long)viol_ep;
+            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
             if (autoreset) {
                 double rn[KR];
                 Env::draw_init(key, rn);
                 Env::init(rn, n);
-                ctr = 0u; fl |= NIG_FLAG_DID_RESET;
+                ctr = 0u;
             } else {
                 ctr |= NIG_CTR_DONE;
             }
         }
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k] = n[k];
-        if (p.reward) (p.reward + base + orow)[tid] = (float)res.reward;
-        if (p.flags) (p.flags + base + orow)[tid] = fl;
+    };
+
+    // no conditional inside the loop: a phi on the action registers would put register copies (and
+    // with them the wait for the freshest loads) on the back edge
+    int it = 0;
+    for (; it + 1 < q.n_steps; it += 2) {
+        one_step(bufA, it);
+        one_step(bufB, it + 1);
     }
+    if (it < q.n_steps) one_step(bufA, it);
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld)[tid] = s[k];
     (p.ctr + base)[tid] = ctr;
-    if (p.tally) (p.ep_ret + base)[tid] = ret;
+    if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
+    if (tally) {
+        (p.ep_ret + base)[tid] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld);
+    }
 }
 
 struct ResetArgs {
@@ -542,6 +642,26 @@ static void launch_step(const StepArgs &a, bool parity, hipStream_t st)
 {
     if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
+}
+
+template <class Env>
+static void launch_rollout_env(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
+{
+    switch (out_mode) {
+    case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 2: hipLaunchKernelGGL((rollout_kernel<Env, 2>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    default: hipLaunchKernelGGL((rollout_kernel<Env, 3>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    }
+}
+
+static void launch_rollout(int env, int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
+{
+    switch (env) {
+    case NIG_ENV_CHEMICAL_REACTOR: launch_rollout_env<ChemicalReactor>(out_mode, q, grid, st); break;
+    case NIG_ENV_POWER_GRID: launch_rollout_env<PowerGrid>(out_mode, q, grid, st); break;
+    default: launch_rollout_env<RobotAssembly>(out_mode, q, grid, st); break;
+    }
 }
 
 static StepArgs base_step_args(const nig_handle *h)
@@ -770,8 +890,11 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
     if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
         return fail(NIG_ERR_INVALID, "nig_rollout: out_stride outside {0} U [batch, 2^26]%s");
     if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: n_steps*out_stride >= 2^32%s");
-    if (obs_out && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH || obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs))
+    const bool obs_aos = obs_out && ld_obs == 0;
+    if (obs_out && !obs_aos && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH || obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs))
         return fail(NIG_ERR_INVALID, "nig_rollout: bad observation trajectory pitch%s");
+    if (obs_aos && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
+        return fail(NIG_ERR_INVALID, "nig_rollout: row-major trajectory needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
     if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: launch counter would wrap%s");
     RolloutArgs q;
     memset(&q, 0, sizeof q);
@@ -780,13 +903,14 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
     q.s.reward = reward_out; q.s.flags = flags_out;
     q.s.t_ptr = nullptr; q.s.t_off = h->t;
     q.n_steps = n_steps; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
-    q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride;
+    q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = obs_aos ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR: hipLaunchKernelGGL((rollout_kernel<ChemicalReactor>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    case NIG_ENV_POWER_GRID: hipLaunchKernelGGL((rollout_kernel<PowerGrid>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    default: hipLaunchKernelGGL((rollout_kernel<RobotAssembly>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    }
+    if ((reward_out == nullptr) != (flags_out == nullptr))
+        return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
+    if (obs_out && !reward_out)
+        return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
+    const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
+    launch_rollout(h->env, out_mode, q, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;

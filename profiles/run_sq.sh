@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: bash profiles/run_sq.sh <tag> [bench args...]   -- SQ issue/stall counters (own pass, no tracing)
+set -e
+tag=$1; shift
+out=gpurun_out/sq_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api "$@" > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
+f=$(find $out -name "*counter_collection.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'rollout_kernel' in r['Kernel_Name'] or 'step_kernel' in r['Kernel_Name']:
+        acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        v = sorted(v); print("   %-22s median %.4g  (n=%d)" % (c, v[len(v)//2], len(v)))
+PY
