@@ -30,6 +30,7 @@ __device__ __forceinline__ T sum8(const T (&x)[8])
 // =================================================================================
 struct ChemicalReactor {
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
+    static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
 
     // chemical_reactor.py:38-60 (penalty, critical) in list order
@@ -135,6 +136,7 @@ struct ChemicalReactor {
 // =================================================================================
 struct PowerGrid {
     static constexpr int ID = 1, S = 32, A = 8, KS = 23, KR = 31, MAX_STEPS = 1000;
+    static constexpr bool COMPACT_RESET = true;    // ~18 % of lanes finish per step (episodes of ~6 steps)
     using reward_t = double;  // float(total_reward), :177
 
     __device__ static constexpr double penalty(int k) { return k == 0 ? -50.0 : (k == 1 ? -30.0 : -20.0); }  // :53-72
@@ -268,6 +270,7 @@ struct PowerGrid {
 // =================================================================================
 struct RobotAssembly {
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
+    static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
     using reward_t = double;
 
     __device__ static constexpr double penalty(int k) { return k == 0 ? -100.0 : (k == 1 ? -200.0 : -50.0); }  // :56-75

@@ -326,21 +326,35 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     using R = typename Env::reward_t;
+    // Envs whose episodes are short (PowerGrid ~6 steps, RobotAssembly: most waves see a reset
+    // every step) compact the finishing lanes of the 256-lane block through LDS each step and let
+    // ONE wave produce all their initial states at full lane utilisation; the owners read them
+    // back from LDS.  Costs two block barriers per step, saves running the whole reset path in
+    // every wave for a few active lanes.  ChemicalReactor (0.3 % of lanes per step) keeps the
+    // barrier-free divergent form.
+    constexpr bool COMPACT = Env::COMPACT_RESET;
+    constexpr int NWAVE = BLOCK / 64;
+    __shared__ float s_init[COMPACT ? S * BLOCK : 1];
+    __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
+    __shared__ int s_cnt[COMPACT ? NWAVE : 1];
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
-    if (base + tid >= p.B) return;
+    const bool in_range = base + tid < p.B;
+    if constexpr (!COMPACT) {
+        if (!in_range) return;       // compacting blocks keep every thread for the barriers
+    }
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
     const uint64_t gi = p.env0 + (uint64_t)(base + tid);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
     const bool tally = p.tally != nullptr;
 
-    uint32_t ctr = (p.ctr + base)[tid];
+    uint32_t ctr = in_range ? (p.ctr + base)[tid] : (uint32_t)NIG_CTR_DONE;   // out-of-range lanes idle as "frozen"
     float s[S], a[A], n[S];
     double nz[KSN];
 #pragma unroll
-    for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld)[tid];
-    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld)[tid] : 0.0f;
+    double ret = (tally && in_range) ? (p.ep_ret + base)[tid] : 0.0;
     LaneTally lt;
     lt.clear();
     // Actions are prefetched TWO steps ahead into two ping-pong register sets (the loop is unrolled
@@ -352,11 +366,11 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     float bufA[A], bufB[A];
     int slot = (q.ring_len > 1) ? 1 : 0;
 #pragma unroll
-    for (int k = 0; k < A; ++k) bufA[k] = (ring + k * p.ld_act)[tid];
+    for (int k = 0; k < A; ++k) bufA[k] = in_range ? (ring + k * p.ld_act)[tid] : 0.0f;
     {
         const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
-        for (int k = 0; k < A; ++k) bufB[k] = (nx + k * p.ld_act)[tid];
+        for (int k = 0; k < A; ++k) bufB[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
     }
     // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
     // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
@@ -401,8 +415,9 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         {
             const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
-            for (int k = 0; k < A; ++k) abuf[k] = (nx + k * p.ld_act)[tid];
+            for (int k = 0; k < A; ++k) abuf[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
         }
+        if (in_range) {
         if constexpr (OUT == 3) {
             // row-major transitions [step][lane][S] (the D4RL "observations[N,S]" layout): each lane
             // owns 4*S contiguous bytes, written as S/4 16-byte stores (12 dword stores -> 3 for CR)
@@ -419,16 +434,48 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
             (p.reward + base + orow)[tid] = rew;
             (p.flags + base + orow)[tid] = fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
         }
+        }   // in_range
         if (done) {
             lt.life += (long long)viol_ep;
             if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
-            if (autoreset) {
+            if (!autoreset) ctr |= NIG_CTR_DONE;
+        }
+        if constexpr (!COMPACT) {
+            if (done && autoreset) {               // divergent per-lane reset (base.py:133-155)
                 double rn[KR];
                 Env::draw_init(key, rn);
                 Env::init(rn, n);
                 ctr = 0u;
-            } else {
-                ctr |= NIG_CTR_DONE;
+            }
+        } else if (autoreset) {                    // block-uniform
+            const unsigned wave = tid >> 6, lane = tid & 63u;
+            const unsigned long long m = __ballot(done);
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[wave] = __popcll(m);
+            if (done) s_list[wave * 64 + rank] = (unsigned short)tid;
+            __syncthreads();
+            int cnt[NWAVE], total = 0, mine = rank;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { cnt[w] = s_cnt[w]; mine += ((unsigned)w < wave) ? cnt[w] : 0; total += cnt[w]; }
+            // the worker role rotates over the block's waves so no SIMD carries it every step
+            const unsigned widx = (tid + BLOCK - 64u * ((unsigned)it & (NWAVE - 1))) & (BLOCK - 1);
+            for (int j = (int)widx; j < total; j += BLOCK) {
+                int w = 0, r = j;
+#pragma unroll
+                for (int qq = 0; qq < NWAVE - 1; ++qq) { const bool nxt = (w == qq) && (r >= cnt[qq]); r = nxt ? r - cnt[qq] : r; w = nxt ? qq + 1 : w; }
+                const unsigned tl = s_list[w * 64 + r];
+                double rn[KR];
+                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi), rn);
+                float r0[S];
+                Env::init(rn, r0);
+#pragma unroll
+                for (int k = 0; k < S; ++k) s_init[k * BLOCK + j] = r0[k];
+            }
+            __syncthreads();
+            if (done) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) n[k] = s_init[k * BLOCK + mine];
+                ctr = 0u;
             }
         }
 #pragma unroll
@@ -443,6 +490,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         one_step(bufB, it + 1);
     }
     if (it < q.n_steps) one_step(bufA, it);
+    if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld)[tid] = s[k];
     (p.ctr + base)[tid] = ctr;
