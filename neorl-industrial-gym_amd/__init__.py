@@ -15,13 +15,13 @@ from .core import DatasetQuality, SafetyConstraint, SafetyMetrics
 
 _lib.lib()   # fail loudly here if libnig.so is missing
 
-from .batched import BatchedIndustrialEnv, StepInfo  # noqa: E402
+from .batched import BatchedIndustrialEnv, MixedBatchedEnv, StepInfo  # noqa: E402
 from .envs import ChemicalReactorEnv, IndustrialEnv, PowerGridEnv, RobotAssemblyEnv  # noqa: E402
 from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
 
 __version__ = "0.1.0"
 __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
-    "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "BatchedIndustrialEnv", "StepInfo",
+    "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "BatchedIndustrialEnv", "MixedBatchedEnv", "StepInfo",
     "make", "make_batched", "evaluate_with_safety",
 ]

@@ -22,7 +22,7 @@ SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
     "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
-    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout",
+    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
     L.nig_plan_create.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, C.POINTER(vp)]
     L.nig_plan_launch.argtypes = [vp, vp]
     L.nig_plan_destroy.argtypes = [vp]
+    L.nig_bind_state.argtypes = [vp, vp, i64]
     L.nig_rollout.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
     _lib = L
     return L

@@ -99,7 +99,7 @@ class BatchedIndustrialEnv:
 
     def __init__(self, env_id: str, batch: int, device="cuda:0", seed: int = 0x5EED, env_index0: int = 0,
                  max_episode_steps: Optional[int] = None, dt: Optional[float] = None, autoreset: bool = True,
-                 tally: bool = False):
+                 tally: bool = False, bind_state: Optional[torch.Tensor] = None):
         if env_id not in ENV_IDS:
             available = ", ".join(ENV_IDS.keys())
             raise ValueError(f"Unknown environment '{env_id}'. Available: {available}")
@@ -137,7 +137,15 @@ class BatchedIndustrialEnv:
         def view(off, nbytes, dtype):
             return self._ws[off:off + nbytes].view(dtype)
 
-        self.state_soa = view(lay.off_state, S * ld * 4, torch.float32).view(S, ld)[:, :B]   # [S, B]
+        if bind_state is None:
+            self.state_soa = view(lay.off_state, S * ld * 4, torch.float32).view(S, ld)[:, :B]   # [S, B]
+        else:
+            # caller-owned padded SoA array (mixed batches): a [>=S, B] float32 view with unit column stride
+            assert bind_state.dtype == torch.float32 and bind_state.device == self.device
+            assert bind_state.shape[0] >= S and bind_state.shape[1] == B and bind_state.stride(1) == 1
+            _lib.check(self._L.nig_bind_state(self._h, C.c_void_p(bind_state.data_ptr()), bind_state.stride(0)))
+            self._bound = bind_state
+            self.state_soa = bind_state[:S]
         self.obs = self.state_soa.t()                                                       # [B, S] strided view
         self.ctr = view(lay.off_ctr, ld * 4, torch.int32)[:B]
         self.life_viol = view(lay.off_life_viol, ld * 8, torch.int64)[:B]
@@ -403,3 +411,83 @@ class StepPlan:
             self.close()
         except Exception:
             pass
+
+
+class MixedBatchedEnv:
+    """Several env types in one padded batch (BASELINE config "all envs mixed-batch, heterogeneous
+    state dims, padded SoA").  Lanes are grouped in contiguous, 256-aligned segments, one env type
+    each (every wavefront is homogeneous); all segments share ONE observation matrix
+    `state_soa` [S_max, LD] (rows >= S of a segment stay zero) and one action matrix layout
+    [A_max, LD].  Each segment is a BatchedIndustrialEnv bound to its columns; a step or rollout
+    launches one kernel per segment, each on its own HIP stream."""
+
+    def __init__(self, segments, device="cuda:0", seed: int = 0x5EED, autoreset: bool = True, tally: bool = False,
+                 env_index0: int = 0):
+        self.device = torch.device(device)
+        segs = list(segments.items()) if isinstance(segments, dict) else list(segments)
+        self.S_max = max(int(_lib.env_spec(ENV_IDS[e]).state_dim) for e, _ in segs)
+        self.A_max = max(int(_lib.env_spec(ENV_IDS[e]).action_dim) for e, _ in segs)
+        offs, off = [], 0
+        for _, n in segs:
+            offs.append(off)
+            off += (int(n) + 255) // 256 * 256
+        self.ld = off
+        self.batch = sum(int(n) for _, n in segs)
+        self.state_soa = torch.zeros(self.S_max, self.ld, dtype=torch.float32, device=self.device)
+        self.obs = self.state_soa.t()
+        self.reward = torch.zeros(self.ld, dtype=torch.float32, device=self.device)
+        self.flags = torch.zeros(self.ld, dtype=torch.int32, device=self.device)
+        self.offsets = offs
+        self.envs = []
+        for (e, n), o in zip(segs, offs):
+            self.envs.append(BatchedIndustrialEnv(e, int(n), device=device, seed=seed, env_index0=env_index0 + o,
+                                                  autoreset=autoreset, tally=tally,
+                                                  bind_state=self.state_soa[:, o:o + int(n)]))
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in self.envs]
+
+    def _fan(self, fn):
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event(); ev.record(cur)
+        for env, st, o in zip(self.envs, self._streams, self.offsets):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                fn(env, o)
+            done = torch.cuda.Event(); done.record(st)
+            cur.wait_event(done)
+
+    def reset(self):
+        self._fan(lambda env, o: env.reset())
+        return self.obs
+
+    def step(self, actions_soa: torch.Tensor):
+        """actions_soa: float32 [A_max, LD] (rows >= A of a segment ignored).  Returns the padded
+        (obs view [LD, S_max], reward [LD], flags [LD])."""
+        assert actions_soa.shape == (self.A_max, self.ld) and actions_soa.stride(1) == 1
+
+        def f(env, o):
+            env.step(actions_soa[:env.action_dim, o:o + env.batch], layout="soa")
+            self.reward[o:o + env.batch].copy_(env.reward)
+            self.flags[o:o + env.batch].copy_(env.flags)
+        self._fan(f)
+        return self.obs, self.reward, self.flags
+
+    def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out=None, flags_out=None):
+        """action_ring: float32 [R, A_max, LD]; optional reward/flags outputs [n_steps, LD]."""
+        assert action_ring.shape[1:] == (self.A_max, self.ld)
+
+        def f(env, o):
+            env.rollout(n_steps, action_ring[:, :env.action_dim, o:o + env.batch],
+                        None if reward_out is None else reward_out[:, o:o + env.batch],
+                        None if flags_out is None else flags_out[:, o:o + env.batch])
+        self._fan(f)
+
+    def fill_actions(self, t: int, out: torch.Tensor):
+        self._fan(lambda env, o: env.fill_actions(t, out[:env.action_dim, o:o + env.batch]))
+        return out
+
+    def reduce_tally(self):
+        return [env.reduce_tally() for env in self.envs]
+
+    def close(self):
+        for e in self.envs:
+            e.close()

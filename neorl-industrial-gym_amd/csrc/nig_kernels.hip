@@ -28,6 +28,7 @@ struct StepArgs {
     // library-owned
     float *state; uint32_t *ctr; long long *life_viol; double *ep_ret; double *tally;
     uint32_t ld; uint32_t B;          // 32-bit on purpose: row offsets k*ld stay in scalar registers
+    uint32_t ld_state;                // pitch of the state rows (== ld unless the caller bound its own array)
     // caller-owned
     const float *actions; uint32_t ld_act;
     const double *step_noise; const double *reset_noise; uint32_t ld_noise;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
     if (in_range) {
         ctr = ctr_row[tid];
 #pragma unroll
-        for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld)[tid];
+        for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld_state)[tid];
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = (act_row + k * p.ld_act)[tid];
         if constexpr (PARITY && KS > 0) {
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
         if (!need_reset) {                        // a resetting lane's state is written by the compacted pass below
             float *so = p.state + base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) (so + k * p.ld)[tid] = n[k];
+            for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
         }
         (p.ctr + base)[tid] = nctr;
         if (p.tally) (p.ep_ret + base)[tid] = ret;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
         Env::init(rn, r0);
         float *so = p.state + base;
 #pragma unroll
-        for (int k = 0; k < S; ++k) (so + k * p.ld)[tl] = r0[k];
+        for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tl] = r0[k];
     }
 }
 
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     float s[S], a[A], n[S];
     double nz[KSN];
 #pragma unroll
-    for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld)[tid] : 0.0f;
+    for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld_state)[tid] : 0.0f;
     double ret = (tally && in_range) ? (p.ep_ret + base)[tid] : 0.0;
     LaneTally lt;
     lt.clear();
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     if (it < q.n_steps) one_step(bufA, it);
     if (!in_range) return;
 #pragma unroll
-    for (int k = 0; k < S; ++k) (p.state + base + k * p.ld)[tid] = s[k];
+    for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
     (p.ctr + base)[tid] = ctr;
     if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
     if (tally) {
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
 
 struct ResetArgs {
     float *state; uint32_t *ctr; long long *life_viol; double *ep_ret;
-    int64_t ld; int64_t B;
+    int64_t ld; int64_t B; int64_t ld_state;
     const uint8_t *mask; const double *noise; int64_t ld_noise;
     uint64_t env0; uint32_t seed_lo, seed_hi, t;
 };
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(BLOCK) reset_kernel(const ResetArgs p)
     float s[S];
     Env::init(rn, s);
 #pragma unroll
-    for (int k = 0; k < S; ++k) p.state[(int64_t)k * p.ld + i] = s[k];
+    for (int k = 0; k < S; ++k) p.state[(int64_t)k * p.ld_state + i] = s[k];
     const uint32_t ctr = p.ctr[i];
     // violations of an abandoned (not finished) episode still belong to total_violations
     if (!(ctr & NIG_CTR_DONE)) p.life_viol[i] += (long long)(ctr >> NIG_CTR_VIOL_SHIFT);
@@ -646,6 +647,8 @@ struct nig_handle {
     bool owns_ws;
     double *scratch;       // reduce scratch [REDUCE_BLOCKS][NIG_T_ROWS] (inside workspace tail)
     uint32_t *t_dev;       // device copy of t read by graph-replayed step kernels
+    float *state;          // state rows: inside the workspace, or an array bound by the caller
+    int64_t ld_state;
 };
 
 struct nig_plan {
@@ -717,7 +720,7 @@ static StepArgs base_step_args(const nig_handle *h)
     const nig_layout &L = h->lay;
     StepArgs a;
     memset(&a, 0, sizeof a);
-    a.state = (float *)(h->ws + L.off_state); a.ctr = (uint32_t *)(h->ws + L.off_ctr);
+    a.state = h->state; a.ld_state = (uint32_t)h->ld_state; a.ctr = (uint32_t *)(h->ws + L.off_ctr);
     a.life_viol = (long long *)(h->ws + L.off_life_viol);
     a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
     a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
@@ -824,6 +827,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     }
     h->scratch = (double *)(h->ws + h->lay.bytes - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - 256);
+    h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
                        (uint32_t *)(h->ws + L.off_ctr), (long long *)(h->ws + L.off_life_viol),
@@ -865,6 +869,16 @@ int nig_get_counter(const nig_handle *h, uint32_t *t)
     return NIG_OK;
 }
 
+int nig_bind_state(nig_handle *h, float *state, int64_t ld)
+{
+    if (!h) return fail(NIG_ERR_INVALID, "nig_bind_state: NULL handle%s");
+    if (!state) { h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld; return NIG_OK; }
+    if (ld < h->B || ld > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_bind_state: ld outside [batch, 2^26]%s");
+    if (((uintptr_t)state & 3u) != 0) return fail(NIG_ERR_INVALID, "nig_bind_state: unaligned pointer%s");
+    h->state = state; h->ld_state = ld;
+    return NIG_OK;
+}
+
 int nig_set_constraint_mask(nig_handle *h, uint32_t mask)
 {
     if (!h) return fail(NIG_ERR_INVALID, "nig_set_constraint_mask: NULL handle%s");
@@ -885,7 +899,7 @@ int nig_reset(nig_handle *h, const uint8_t *mask, const double *init_noise, int6
     if (init_noise && ld_noise < h->B) return fail(NIG_ERR_INVALID, "nig_reset: ld_noise < batch%s");
     const nig_layout &L = h->lay;
     ResetArgs a;
-    a.state = (float *)(h->ws + L.off_state); a.ctr = (uint32_t *)(h->ws + L.off_ctr);
+    a.state = h->state; a.ld_state = h->ld_state; a.ctr = (uint32_t *)(h->ws + L.off_ctr);
     a.life_viol = (long long *)(h->ws + L.off_life_viol);
     a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
     a.ld = L.ld; a.B = h->B; a.mask = mask; a.noise = init_noise; a.ld_noise = ld_noise;
@@ -1052,7 +1066,7 @@ int nig_set_state(nig_handle *h, const float *state, int64_t ld, const uint32_t 
     if (state) {
         if (ld < h->B) return fail(NIG_ERR_INVALID, "nig_set_state: ld < batch%s");
         hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, state, ld,
-                           (float *)(h->ws + L.off_state), L.ld, SPECS[h->env].state_dim, h->B);
+                           h->state, h->ld_state, SPECS[h->env].state_dim, h->B);
         HIP_TRY(hipGetLastError());
     }
     if (ctr) HIP_TRY(hipMemcpyAsync(h->ws + L.off_ctr, ctr, (size_t)h->B * 4, hipMemcpyDeviceToDevice, st));
@@ -1067,7 +1081,7 @@ int nig_get_state(nig_handle *h, float *state, int64_t ld, uint32_t *ctr, void *
     if (state) {
         if (ld < h->B) return fail(NIG_ERR_INVALID, "nig_get_state: ld < batch%s");
         hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st,
-                           (const float *)(h->ws + L.off_state), L.ld, state, ld, SPECS[h->env].state_dim, h->B);
+                           (const float *)h->state, h->ld_state, state, ld, SPECS[h->env].state_dim, h->B);
         HIP_TRY(hipGetLastError());
     }
     if (ctr) HIP_TRY(hipMemcpyAsync(ctr, h->ws + L.off_ctr, (size_t)h->B * 4, hipMemcpyDeviceToDevice, st));
