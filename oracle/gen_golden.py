@@ -595,5 +595,28 @@ def main():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "datasets"):
     main()
+
+
+def gen_dataset_fixtures():
+    """get_dataset() heads + summary statistics from a seeded reference run (np.random.seed(123))."""
+    utils = load_reference()
+    out = {}
+    for key, name in ENVS.items():
+        for q in (("expert",) if key == "cr" else ("expert", "random", "mixed")):
+            env = utils.make(name)
+            np.random.seed(123)
+            d = env.get_dataset(q)
+            n = len(d["rewards"])
+            out[f"{key}_{q}_n"] = np.array(n)
+            out[f"{key}_{q}_reward_mean"] = np.array(float(d["rewards"].astype(np.float64).mean()))
+            out[f"{key}_{q}_n_terminals"] = np.array(int(d["terminals"].sum()))
+            for k in ("observations", "actions", "rewards", "terminals"):
+                out[f"{key}_{q}_{k}"] = d[k][:160]
+            print(key, q, n, float(d["rewards"].mean()), int(d["terminals"].sum()))
+    np.savez_compressed(os.path.join(OUT, "datasets.npz"), **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "datasets":
+    gen_dataset_fixtures()
