@@ -231,6 +231,55 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
                 int64_t out_stride, float *obs_out, int64_t ld_obs, int64_t obs_step_stride,
                 void *stream);
 
+/*
+ * Closed-loop rollouts with an on-device policy ("nig-policy-v1").  The policy
+ * families are the reference's non-neural ones: the baseline agents Constant / "MPC"
+ * (proportional) / PID / Random (benchmarks/baseline_agents.py:28-114) and the behaviour
+ * policies of get_dataset (chemical_reactor.py:364-393, power_grid.py:216-233,
+ * robot_assembly.py:266-290): an affine map of the observation, plus per-dimension Gaussian
+ * and uniform noise, an epsilon-mixture with a uniform random action, and a clip.
+ * All arithmetic is float32, terms in ascending (k, then j) order, zero columns skipped:
+ *     u_j = b_j + sum_k Wt[k][j] * obs[k]                       (kind AFFINE)
+ *     e_j = setpoint_j - obs[j]; I_j += e_j; u_j = kp*e_j + ki*I_j + kd*(e_j - eprev_j)   (kind PID)
+ *     u_j += sigma_j * z_j + half_range_j * (2*v_j - 1)          z ~ N(0,1), v ~ U[0,1)
+ *     if (w < p_uniform) u_j = uniform_range * (2*r_j - 1)       w, r ~ U[0,1)
+ *     a_j = min(max(u_j, clip_lo), clip_hi)                      then IndustrialEnv.step clips to [-1,1]
+ * Random draws come from generator stream "policy" at (global lane, launch counter t).
+ */
+#define NIG_POLICY_AFFINE 1
+#define NIG_POLICY_PID 2
+typedef struct nig_policy {
+    int32_t kind;
+    uint32_t colmask;        /* bit k set: observation column k has a non-zero weight (host-computed) */
+    float Wt[32][8];         /* Wt[k][j] = weight of obs[k] in action j                           */
+    float b[8];
+    float sigma[8];
+    float half_range[8];
+    float p_uniform, uniform_range;
+    float clip_lo, clip_hi;
+    float kp, ki, kd;
+    float setpoint[8];
+} nig_policy;
+
+/* Install the policy used by nig_rollout_policy (copied to device memory owned by the handle). */
+int nig_set_policy(nig_handle *h, const nig_policy *policy /* host */, void *stream);
+
+/*
+ * n_steps closed-loop steps per lane in one launch: action = policy(observation), then
+ * IndustrialEnv.step, state in registers.  Optional per-step outputs (any subset):
+ *   obs_out   float row-major [n_steps][B][S]: the observation the policy acted on (D4RL
+ *             'observations'), step k at obs_out + k*obs_step_stride
+ *   act_out   float [n_steps][A][ld_act]: the policy's action (after its own clip, before the
+ *             env's), step k at act_out + k*act_step_stride
+ *   reward_out / flags_out   row of step k at base + k*out_stride (0 = overwrite)
+ * Frozen lanes (finished, no auto-reset) write NIG_FLAG_INACTIVE and leave obs/act rows untouched.
+ * This is the loop of utils.evaluate_with_safety (utils.py:80-112) and of the get_dataset
+ * generators, with the agent on the device.
+ */
+int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out,
+                       int64_t out_stride, float *obs_out, int64_t obs_step_stride,
+                       float *act_out, int64_t ld_act, int64_t act_step_stride, void *stream);
+
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);

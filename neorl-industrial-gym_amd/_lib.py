@@ -22,7 +22,7 @@ SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
     "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
-    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state",
+    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy",
 ]
 
 
@@ -37,6 +37,17 @@ class Layout(C.Structure):
     _fields_ = [("batch", C.c_int64), ("ld", C.c_int64), ("bytes", C.c_int64), ("off_state", C.c_int64),
                 ("off_ctr", C.c_int64), ("off_life_viol", C.c_int64), ("off_ep_return", C.c_int64),
                 ("off_tally", C.c_int64)]
+
+
+class Policy(C.Structure):
+    """nig_policy (include/nig.h, "nig-policy-v1")."""
+    _fields_ = [("kind", C.c_int32), ("colmask", C.c_uint32), ("Wt", (C.c_float * 8) * 32), ("b", C.c_float * 8),
+                ("sigma", C.c_float * 8), ("half_range", C.c_float * 8), ("p_uniform", C.c_float),
+                ("uniform_range", C.c_float), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+                ("kp", C.c_float), ("ki", C.c_float), ("kd", C.c_float), ("setpoint", C.c_float * 8)]
+
+
+POLICY_AFFINE, POLICY_PID = 1, 2
 
 
 class NigError(RuntimeError):
@@ -86,6 +97,8 @@ def lib():
     L.nig_plan_launch.argtypes = [vp, vp]
     L.nig_plan_destroy.argtypes = [vp]
     L.nig_bind_state.argtypes = [vp, vp, i64]
+    L.nig_set_policy.argtypes = [vp, C.POINTER(Policy), vp]
+    L.nig_rollout_policy.argtypes = [vp, i32, vp, vp, i64, vp, i64, vp, i64, i64, vp]
     L.nig_rollout.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
     _lib = L
     return L

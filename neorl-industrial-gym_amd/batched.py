@@ -323,6 +323,92 @@ class BatchedIndustrialEnv:
             _lib.check(self._L.nig_rollout(self._h, int(n_steps), C.c_void_p(action_ring.data_ptr()), ld,
                                            action_ring.stride(0), R, rp, fp, rs or fs, op, ldo, so, self._stream()))
 
+    # ------------------------------------------------------------------
+    def set_policy(self, policy):
+        """Install an on-device policy (policies.DevicePolicy) for rollout_policy()."""
+        P = policy.to_struct() if hasattr(policy, "to_struct") else policy
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_set_policy(self._h, C.byref(P), self._stream()))
+        self._policy = policy
+
+    def rollout_policy(self, n_steps: int, reward_out: Optional[torch.Tensor] = None,
+                       flags_out: Optional[torch.Tensor] = None, obs_out: Optional[torch.Tensor] = None,
+                       act_out: Optional[torch.Tensor] = None):
+        """n_steps closed-loop steps (action = installed policy(observation)) in ONE launch.
+        obs_out: float32 contiguous [n_steps, B, S] (observation the policy acted on);
+        act_out: float32 [n_steps, A, >=B]; reward_out / flags_out: [n_steps, >=B] or [B]."""
+        def out(t, dtype):
+            if t is None:
+                return None, 0
+            assert t.dtype == dtype and t.stride(-1) == 1
+            if t.dim() == 2:
+                assert t.shape[0] >= n_steps
+                return C.c_void_p(t.data_ptr()), t.stride(0)
+            return C.c_void_p(t.data_ptr()), 0
+
+        rp, rs = out(reward_out, torch.float32)
+        fp, fs = out(flags_out, torch.int32)
+        assert rp is None or fp is None or rs == fs
+        op, so = None, 0
+        if obs_out is not None:
+            assert obs_out.dtype == torch.float32 and obs_out.is_contiguous()
+            assert obs_out.shape[0] >= n_steps and obs_out.shape[1:] == (self.batch, self.state_dim)
+            op, so = C.c_void_p(obs_out.data_ptr()), obs_out.stride(0)
+        ap, lda, sa = None, 0, 0
+        if act_out is not None:
+            assert act_out.dtype == torch.float32 and act_out.dim() == 3 and act_out.stride(2) == 1
+            assert act_out.shape[0] >= n_steps and act_out.shape[1] == self.action_dim and act_out.shape[2] >= self.batch
+            ap, lda, sa = C.c_void_p(act_out.data_ptr()), act_out.stride(1), act_out.stride(0)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_rollout_policy(self._h, int(n_steps), rp, fp, rs or fs, op, so, ap, lda, sa,
+                                                  self._stream()))
+
+    def get_dataset(self, quality: str = "mixed", scale: int = 1, chunk: int = 100):
+        """Batched env.get_dataset(quality): every lane is one episode of the reference's
+        data-collection loop (chemical_reactor.py:324-420, power_grid.py:194-249,
+        robot_assembly.py:246-308) driven by the on-device behaviour policy; `scale` multiplies
+        the upstream episode count.  Needs batch >= episodes*scale and autoreset=False.
+        Returns the D4RL-style dict as torch tensors on the device (episode-major order)."""
+        from .policies import DATASET_SHAPE, behaviour_policy
+        assert not self.autoreset, "dataset generation needs autoreset=False (one episode per lane)"
+        n_eps, cap = DATASET_SHAPE[self.env_id][quality]
+        n_eps *= int(scale)
+        if n_eps > self.batch:
+            raise ValueError(f"batch {self.batch} < {n_eps} episodes")
+        B, S, A = self.batch, self.state_dim, self.action_dim
+        self.set_policy(behaviour_policy(self.env_id, quality))
+        mask = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        mask[:n_eps] = 1
+        self.ctr.fill_(_lib.CTR_DONE)                 # lanes beyond n_eps stay idle
+        self.reset(mask=mask)
+        obs_c, act_c, rew_c, live_c, term_c = [], [], [], [], []
+        done_steps = 0
+        while done_steps < cap:
+            T = min(chunk, cap - done_steps)
+            obs = torch.empty(T, B, S, dtype=torch.float32, device=self.device)
+            act = torch.empty(T, A, self.ld, dtype=torch.float32, device=self.device)
+            rew = torch.empty(T, self.ld, dtype=torch.float32, device=self.device)
+            fl = torch.empty(T, self.ld, dtype=torch.int32, device=self.device)
+            self.rollout_policy(T, rew, fl, obs, act)
+            live = (fl[:, :n_eps] & _lib.FLAG_INACTIVE) == 0
+            obs_c.append(obs[:, :n_eps]); act_c.append(act[:, :, :n_eps]); rew_c.append(rew[:, :n_eps])
+            live_c.append(live)
+            both = (fl[:, :n_eps] & (_lib.FLAG_TERMINATED | _lib.FLAG_TRUNCATED)) != 0
+            term_c.append(both if self.env_id == "ChemicalReactor-v0" else (fl[:, :n_eps] & _lib.FLAG_TERMINATED) != 0)
+            done_steps += T
+            if not bool(live[-1].any().item()):
+                break
+        live = torch.cat(live_c).t()                                  # [episodes, steps] -> episode-major
+        sel = live.reshape(-1)
+        obs = torch.cat(obs_c).permute(1, 0, 2).reshape(-1, S)[sel]
+        act = torch.cat(act_c).permute(2, 0, 1).reshape(-1, A)[sel]
+        rew = torch.cat(rew_c).t().reshape(-1)[sel]
+        term = torch.cat(term_c).t().reshape(-1)[sel]
+        out = {"observations": obs, "actions": act, "rewards": rew, "terminals": term}
+        if self.env_id == "ChemicalReactor-v0":
+            out["timeouts"] = torch.zeros_like(term)
+        return out
+
     def fill_actions(self, t: int, out: Optional[torch.Tensor] = None):
         """Synthetic uniform [-1,1) actions of the bench workload for launch counter t -> [A, B]."""
         if out is None:

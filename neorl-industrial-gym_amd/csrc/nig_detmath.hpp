@@ -138,6 +138,7 @@ __device__ __forceinline__ void det_sincos(double x, double &s, double &c)
 constexpr uint32_t STREAM_STEP = 0u;
 constexpr uint32_t STREAM_RESET = 0x40000000u;
 constexpr uint32_t STREAM_ACTION = 0x80000000u;
+constexpr uint32_t STREAM_POLICY = 0xC0000000u;   // +0: mixture draw, +1..: normals, +8..: uniform noise, +16..: random action
 
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -185,6 +186,8 @@ __device__ __forceinline__ void bm_pair(uint32_t x0, uint32_t x1, float &z0, flo
     det_sincos2pi_u24(x1 >> 8, s, c);
     z0 = r * c; z1 = r * s;
 }
+
+__device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // exact in float32
 
 __device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
 

@@ -23,6 +23,7 @@ namespace nig {
 
 constexpr int BLOCK = 256;
 constexpr int REDUCE_BLOCKS = 256;
+constexpr int64_t POLICY_BYTES = 2048;     // device copy of nig_policy at the workspace tail
 
 struct StepArgs {
     // library-owned
@@ -502,6 +503,177 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Closed-loop fused rollout: action = on-device policy(observation) -> IndustrialEnv.step, n steps
+// per launch, state / counters / tallies / PID memory in registers.  No loads inside the loop
+// (the policy struct is read through the scalar cache), so the optional outputs can stay
+// run-time switches.  Spec of the policy arithmetic: include/nig.h "nig-policy-v1".
+struct PolicyArgs {
+    StepArgs s;
+    const nig_policy *pol;      // device copy
+    int n_steps;
+    uint32_t out_stride;
+    float *obs_out; uint64_t obs_step_stride;                        // row-major [B][S] per step, pre-step obs
+    float *act_out; uint32_t ld_act_out; uint64_t act_step_stride;   // [A][ld] per step
+};
+
+template <class Env>
+__device__ __forceinline__ void policy_action(const nig_policy *__restrict__ P, const float (&obs)[Env::S],
+                                              const RngKey &key, float (&integ)[Env::A], float (&eprev)[Env::A],
+                                              float (&u)[Env::A])
+{
+    constexpr int S = Env::S, A = Env::A;
+    if (P->kind == NIG_POLICY_PID) {               // baseline_agents.py:61-80
+        const float kp = P->kp, ki = P->ki, kd = P->kd;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float e = P->setpoint[j] - obs[j];
+            integ[j] = integ[j] + e;
+            u[j] = (kp * e + ki * integ[j]) + kd * (e - eprev[j]);
+            eprev[j] = e;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = P->b[j];
+        const uint32_t cm = P->colmask;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            if (cm & (1u << k)) {                  // wave-uniform: whole zero columns are skipped
+#pragma unroll
+                for (int j = 0; j < A; ++j) u[j] = u[j] + P->Wt[k][j] * obs[k];
+            }
+        }
+    }
+    bool any_sigma = false, any_half = false;
+#pragma unroll
+    for (int j = 0; j < A; ++j) { any_sigma = any_sigma || (P->sigma[j] != 0.0f); any_half = any_half || (P->half_range[j] != 0.0f); }
+    if (any_sigma) {
+        float z[A];
+        gen_normals<A>(key, STREAM_POLICY + 1u, z);
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = u[j] + P->sigma[j] * z[j];
+    }
+    if (any_half) {
+#pragma unroll
+        for (int b4 = 0; 4 * b4 < A; ++b4) {
+            const u32x4 x = key.block(STREAM_POLICY + 8u + (uint32_t)b4);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * b4 + i < A) u[4 * b4 + i] = u[4 * b4 + i] + P->half_range[4 * b4 + i] * (2.0f * u01f(w[i]) - 1.0f);
+        }
+    }
+    if (P->p_uniform > 0.0f) {
+        const float wmix = u01f(key.block(STREAM_POLICY).x);
+        const bool rnd = wmix < P->p_uniform;
+        const float r = P->uniform_range;
+#pragma unroll
+        for (int b4 = 0; 4 * b4 < A; ++b4) {
+            const u32x4 x = key.block(STREAM_POLICY + 16u + (uint32_t)b4);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * b4 + i < A) { const float ra = r * (2.0f * u01f(w[i]) - 1.0f); u[4 * b4 + i] = rnd ? ra : u[4 * b4 + i]; }
+        }
+    }
+    const float lo = P->clip_lo, hi = P->clip_hi;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {                  // np.clip == minimum(maximum(x, lo), hi)
+        float x = u[j];
+        x = (x < lo) ? lo : x;
+        x = (x > hi) ? hi : x;
+        u[j] = x;
+    }
+}
+
+template <class Env>
+__global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs q)
+{
+    constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
+    constexpr int KSN = KS > 0 ? KS : 1;
+    using R = typename Env::reward_t;
+    const StepArgs &p = q.s;
+    const unsigned tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * BLOCK;
+    if (base + tid >= p.B) return;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
+    const uint64_t gi = p.env0 + (uint64_t)(base + tid);
+    const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
+    const bool tally = p.tally != nullptr;
+
+    uint32_t ctr = (p.ctr + base)[tid];
+    float s[S], a[A], n[S], integ[A], eprev[A];
+    double nz[KSN];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[tid];
+#pragma unroll
+    for (int j = 0; j < A; ++j) { integ[j] = 0.0f; eprev[j] = 0.0f; }
+    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    LaneTally lt;
+    lt.clear();
+
+    for (int it = 0; it < q.n_steps; ++it) {
+        const uint32_t orow = (uint32_t)it * q.out_stride;
+        if (ctr & NIG_CTR_DONE) {                  // frozen lane: base.py:159-160
+            if (p.flags) (p.flags + base + orow)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+            if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
+            continue;
+        }
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        policy_action<Env>(q.pol, s, key, integ, eprev, a);
+        if (q.obs_out) {
+            float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) + (size_t)(base + tid) * (S / 4);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+        }
+        if (q.act_out) {
+            float *ao = q.act_out + (size_t)it * q.act_step_stride + base;
+#pragma unroll
+            for (int j = 0; j < A; ++j) (ao + j * q.ld_act_out)[tid] = a[j];
+        }
+        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+        StepResult<Env> res;
+        step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
+        const int step = step_pre + 1;
+        const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+        const bool done = res.terminated || res.truncated;
+        uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
+                      (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
+                      ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
+                      ((uint32_t)step << NIG_FLAG_STEP_SHIFT) | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
+        ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+        if (tally) {
+            if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
+            else ret = ret + (double)res.reward;
+        }
+        if (p.reward) (p.reward + base + orow)[tid] = (float)res.reward;
+        if (p.flags) (p.flags + base + orow)[tid] = fl;
+        if (done) {
+            lt.life += (long long)viol_ep;
+            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (autoreset) {
+                double rn[KR];
+                Env::draw_init(key, rn);
+                Env::init(rn, n);
+                ctr = 0u;
+            } else {
+                ctr |= NIG_CTR_DONE;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = n[k];
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
+    (p.ctr + base)[tid] = ctr;
+    if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
+    if (tally) {
+        (p.ep_ret + base)[tid] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld);
+    }
+}
+
 struct ResetArgs {
     float *state; uint32_t *ctr; long long *life_viol; double *ep_ret;
     int64_t ld; int64_t B; int64_t ld_state;
@@ -649,6 +821,9 @@ struct nig_handle {
     uint32_t *t_dev;       // device copy of t read by graph-replayed step kernels
     float *state;          // state rows: inside the workspace, or an array bound by the caller
     int64_t ld_state;
+    nig_policy *pol_dev;   // device copy of the installed policy
+    nig_policy pol_host;   // staging copy (must outlive the async H2D copy)
+    bool has_policy;
 };
 
 struct nig_plan {
@@ -782,7 +957,7 @@ int nig_layout_query(int env, int64_t batch, uint32_t flags, nig_layout *out)
         L.off_tally = -1;
     }
     // tail: reduce scratch + the device-resident launch counter used by plans
-    off = align_up(off + (int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256) + 256;
+    off = align_up(off + (int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256) + 256 + POLICY_BYTES;
     L.bytes = off;
     *out = L;
     return NIG_OK;
@@ -825,8 +1000,10 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
         if (me != hipSuccess) { delete h; return fail(NIG_ERR_HIP, "hipMalloc workspace: %s", hipGetErrorString(me)); }
         h->ws = (char *)p; h->owns_ws = true;
     }
-    h->scratch = (double *)(h->ws + h->lay.bytes - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - 256);
+    h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
+    h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
+    h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
+    h->has_policy = false;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -973,6 +1150,59 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
         return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
     const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
     launch_rollout(h->env, out_mode, q, grid_for(h->B), st);
+    HIP_TRY(hipGetLastError());
+    h->t += (uint32_t)n_steps;
+    return NIG_OK;
+}
+
+int nig_set_policy(nig_handle *h, const nig_policy *policy, void *stream)
+{
+    if (!h || !policy) return fail(NIG_ERR_INVALID, "nig_set_policy: NULL argument%s");
+    static_assert(sizeof(nig_policy) <= POLICY_BYTES, "policy struct outgrew its device slot");
+    if (policy->kind != NIG_POLICY_AFFINE && policy->kind != NIG_POLICY_PID)
+        return fail(NIG_ERR_INVALID, "nig_set_policy: unknown policy kind%s");
+    if (!(policy->clip_lo <= policy->clip_hi)) return fail(NIG_ERR_INVALID, "nig_set_policy: clip_lo > clip_hi%s");
+    h->pol_host = *policy;
+    // recompute the non-zero column mask here so a caller cannot get it wrong
+    uint32_t cm = 0;
+    for (int k = 0; k < SPECS[h->env].state_dim; ++k)
+        for (int j = 0; j < SPECS[h->env].action_dim; ++j)
+            if (policy->Wt[k][j] != 0.0f) cm |= (1u << k);
+    h->pol_host.colmask = cm;
+    HIP_TRY(hipMemcpyAsync(h->pol_dev, &h->pol_host, sizeof(nig_policy), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // pageable source: make the staging copy reusable
+    h->has_policy = true;
+    return NIG_OK;
+}
+
+int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                       float *obs_out, int64_t obs_step_stride, float *act_out, int64_t ld_act,
+                       int64_t act_step_stride, void *stream)
+{
+    if (!h || n_steps <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_policy: bad argument%s");
+    if (!h->has_policy) return fail(NIG_ERR_INVALID, "nig_rollout_policy: no policy installed (nig_set_policy)%s");
+    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
+        return fail(NIG_ERR_INVALID, "nig_rollout_policy: out_stride outside {0} U [batch, 2^26]%s");
+    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_policy: n_steps*out_stride >= 2^32%s");
+    if (obs_out && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
+        return fail(NIG_ERR_INVALID, "nig_rollout_policy: obs_out needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
+    if (act_out && (ld_act < h->B || ld_act > NIG_MAX_PITCH || act_step_stride < (int64_t)SPECS[h->env].action_dim * ld_act))
+        return fail(NIG_ERR_INVALID, "nig_rollout_policy: bad action trajectory pitch%s");
+    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_policy: launch counter would wrap%s");
+    PolicyArgs q;
+    memset(&q, 0, sizeof q);
+    q.s = base_step_args(h);
+    q.s.reward = reward_out; q.s.flags = flags_out;
+    q.s.t_ptr = nullptr; q.s.t_off = h->t;
+    q.pol = h->pol_dev; q.n_steps = n_steps; q.out_stride = (uint32_t)out_stride;
+    q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
+    q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
+    hipStream_t st = (hipStream_t)stream;
+    switch (h->env) {
+    case NIG_ENV_CHEMICAL_REACTOR: hipLaunchKernelGGL((rollout_policy_kernel<ChemicalReactor>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    case NIG_ENV_POWER_GRID: hipLaunchKernelGGL((rollout_policy_kernel<PowerGrid>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    default: hipLaunchKernelGGL((rollout_policy_kernel<RobotAssembly>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
+    }
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;

@@ -109,6 +109,18 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
         raise ValueError("batched evaluation needs make_batched(..., tally=True, autoreset=False)")
     B = env.batch
     remaining, rnd = int(n_episodes), 0
+    device_policy = hasattr(agent, "to_struct") and step_noise_fn is None and reset_noise_fn is None
+    if device_policy:
+        env.set_policy(agent)
+    while remaining > 0 and device_policy:
+        # the agent runs ON the device: one fused launch plays every episode of the round to its end
+        k = min(B, remaining)
+        mask = torch.zeros(B, dtype=torch.uint8, device=env.device)
+        mask[:k] = 1
+        env.ctr.fill_(_lib.CTR_DONE)
+        env.reset(mask=mask)
+        env.rollout_policy(env.max_episode_steps)
+        remaining -= k
     while remaining > 0:
         k = min(B, remaining)
         mask = torch.zeros(B, dtype=torch.uint8, device=env.device)

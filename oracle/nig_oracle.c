@@ -743,6 +743,135 @@ void oracle_rollout(int env, int64_t n, uint64_t env0, uint64_t seed, uint32_t t
     if (total) *total = tot;
 }
 
+
+/* ------------------------------------------------------------------------------
+ * On-device policy "nig-policy-v1" (include/nig.h): independent restatement for the
+ * closed-loop cross-checks.  Policy families = the reference's non-neural agents
+ * (benchmarks/baseline_agents.py:28-114) and get_dataset behaviour policies
+ * (chemical_reactor.py:364-393, power_grid.py:216-233, robot_assembly.py:266-290).
+ * ---------------------------------------------------------------------------- */
+#define STREAM_POLICY 0xC0000000u
+typedef struct {
+    int32_t kind; uint32_t colmask;
+    float Wt[32][8]; float b[8]; float sigma[8]; float half_range[8];
+    float p_uniform, uniform_range, clip_lo, clip_hi, kp, ki, kd; float setpoint[8];
+} oracle_policy_t;
+
+static float u01f(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+static void policy_action(int env, const oracle_policy_t *P, const float *obs, uint64_t seed, uint64_t gi, uint32_t t,
+                          float *integ, float *eprev, float *u)
+{
+    const int S = SPECS[env].state_dim, A = SPECS[env].action_dim;
+    if (P->kind == 2) {                                        /* PID, baseline_agents.py:61-80 */
+        for (int j = 0; j < A; j++) {
+            float e = P->setpoint[j] - obs[j];
+            integ[j] = integ[j] + e;
+            u[j] = (P->kp * e + P->ki * integ[j]) + P->kd * (e - eprev[j]);
+            eprev[j] = e;
+        }
+    } else {
+        for (int j = 0; j < A; j++) u[j] = P->b[j];
+        for (int k = 0; k < S; k++) {
+            int nz = 0;
+            for (int j = 0; j < A; j++) if (P->Wt[k][j] != 0.0f) nz = 1;
+            if (!nz) continue;                                 /* zero columns are skipped */
+            for (int j = 0; j < A; j++) u[j] = u[j] + P->Wt[k][j] * obs[k];
+        }
+    }
+    int any_sigma = 0, any_half = 0;
+    for (int j = 0; j < A; j++) { if (P->sigma[j] != 0.0f) any_sigma = 1; if (P->half_range[j] != 0.0f) any_half = 1; }
+    uint32_t x[4];
+    if (any_sigma) {
+        float z[8];
+        gen_normals(seed, gi, t, STREAM_POLICY + 1u, A, z);
+        for (int j = 0; j < A; j++) u[j] = u[j] + P->sigma[j] * z[j];
+    }
+    if (any_half) {
+        for (int b4 = 0; 4 * b4 < A; b4++) {
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), t, STREAM_POLICY + 8u + (uint32_t)b4, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+            for (int i = 0; i < 4 && 4 * b4 + i < A; i++)
+                u[4 * b4 + i] = u[4 * b4 + i] + P->half_range[4 * b4 + i] * (2.0f * u01f(x[i]) - 1.0f);
+        }
+    }
+    if (P->p_uniform > 0.0f) {
+        philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), t, STREAM_POLICY, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        int rnd = u01f(x[0]) < P->p_uniform;
+        for (int b4 = 0; 4 * b4 < A; b4++) {
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), t, STREAM_POLICY + 16u + (uint32_t)b4, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+            for (int i = 0; i < 4 && 4 * b4 + i < A; i++) {
+                float ra = P->uniform_range * (2.0f * u01f(x[i]) - 1.0f);
+                if (rnd) u[4 * b4 + i] = ra;
+            }
+        }
+    }
+    for (int j = 0; j < A; j++) {
+        float v = u[j];
+        v = (v < P->clip_lo) ? P->clip_lo : v;
+        v = (v > P->clip_hi) ? P->clip_hi : v;
+        u[j] = v;
+    }
+}
+
+/* Closed-loop rollout: action = policy(obs) -> step; lanes freeze at done unless autoreset.
+ * Optional trajectories (row-major): obs_pre [T][n][S], act [T][n][A], reward [T][n] (double),
+ * live [T][n] (1 where the lane took the step). */
+void oracle_rollout_policy(int env, int64_t n, uint64_t env0, uint64_t seed, uint32_t t0, int T,
+                           int max_steps, double dt, int flavor, int autoreset, const oracle_policy_t *P,
+                           float *state_out /* [n][S] */, int32_t *step_out, int32_t *done_out,
+                           oracle_tally_t *tally /* [n] */, double *ep_return_last /* [n] last finished */,
+                           float *obs_pre, float *act, double *reward, uint8_t *live)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    const int S = sp->state_dim, A = sp->action_dim;
+    for (int64_t i = 0; i < n; i++) {
+        float s[32], nx[32], a[8], integ[8] = {0}, eprev[8] = {0};
+        double nz[32];
+        uint64_t gi = env0 + (uint64_t)i;
+        oracle_tally_t me; memset(&me, 0, sizeof me);
+        oracle_gen_reset_noise(env, seed, gi, t0, nz);
+        oracle_reset(env, nz, flavor, s);
+        int step = 0, done = 0;
+        double ret = 0.0; float ret32 = 0.0f;
+        if (ep_return_last) ep_return_last[i] = 0.0;
+        for (int k = 0; k < T; k++) {
+            uint32_t t = t0 + 1u + (uint32_t)k;
+            if (live) live[(size_t)k * n + i] = (uint8_t)!done;
+            if (done) continue;
+            policy_action(env, P, s, seed, gi, t, integ, eprev, a);
+            if (obs_pre) memcpy(obs_pre + ((size_t)k * n + i) * S, s, S * sizeof(float));
+            if (act) memcpy(act + ((size_t)k * n + i) * A, a, A * sizeof(float));
+            oracle_step_out_t o;
+            oracle_gen_step_noise(env, seed, gi, t, nz);
+            oracle_step(env, s, a, nz, step, max_steps, dt, flavor, nx, &o);
+            if (reward) reward[(size_t)k * n + i] = o.reward;
+            me.steps++; me.violations += o.violation_count; me.critical += o.critical_violations;
+            me.reward_sum += o.reward;
+            if (env == ORACLE_CR) { ret32 = ret32 + (float)o.reward; ret = (double)ret32; } else ret += o.reward;
+            me.terminated += o.terminated; me.truncated += (o.truncated && !o.terminated);
+            if (o.terminated || o.truncated) {
+                me.episodes++;
+                if (ep_return_last) ep_return_last[i] = ret;
+                ret = 0.0; ret32 = 0.0f;
+                if (autoreset) {
+                    oracle_gen_reset_noise(env, seed, gi, t, nz);
+                    oracle_reset(env, nz, flavor, s);
+                    step = 0;
+                } else {
+                    memcpy(s, nx, S * sizeof(float));
+                    step++; done = 1;
+                }
+            } else {
+                memcpy(s, nx, S * sizeof(float));
+                step++;
+            }
+        }
+        memcpy(state_out + (size_t)i * S, s, S * sizeof(float));
+        step_out[i] = step; done_out[i] = done;
+        if (tally) tally[i] = me;
+    }
+}
+
 /* exposed for unit tests of the math layer */
 float oracle_det_expf(float x) { return det_expf(x); }
 float oracle_det_logf(float x) { return det_logf(x); }
