@@ -872,6 +872,12 @@ void oracle_rollout_policy(int env, int64_t n, uint64_t env0, uint64_t seed, uin
     }
 }
 
+void oracle_policy_action(int env, const oracle_policy_t *P, const float *obs, uint64_t seed, uint64_t gi, uint32_t t,
+                          float *integ, float *eprev, float *u)
+{
+    policy_action(env, P, obs, seed, gi, t, integ, eprev, u);
+}
+
 /* exposed for unit tests of the math layer */
 float oracle_det_expf(float x) { return det_expf(x); }
 float oracle_det_logf(float x) { return det_logf(x); }

@@ -118,3 +118,57 @@ def test_evaluate_requires_trained_agent():
         is_trained = False
     with pytest.raises(RuntimeError, match="Agent must be trained before evaluation"):
         ni.evaluate_with_safety(A(), object(), 1)
+
+
+def test_device_policy_host_predict_matches_oracle_policy(oracle):
+    """DevicePolicy.predict (host float32 mirror of the on-device arithmetic) equals the oracle's
+    restatement of nig-policy-v1 for every deterministic policy family; the struct handed to the
+    device has the oracle's layout."""
+    import ctypes as C
+    import neorl_industrial_gym_amd as ni
+    assert C.sizeof(ni._lib.Policy) == C.sizeof(oracle.Policy)
+    rng = np.random.default_rng(3)
+    for key, name, S, A in (("cr", "ChemicalReactor-v0", 12, 3), ("pg", "PowerGrid-v0", 32, 8), ("ra", "RobotAssembly-v0", 24, 7)):
+        obs = oracle.reset(key, np.stack([oracle.gen_reset_noise(key, 1, i, 0) for i in range(20)]))
+        pols = [ni.behaviour_policy(name, "expert"), ni.mpc_agent(S, A), ni.constant_agent(S, A, rng.uniform(-1, 1, A)),
+                ni.DevicePolicy(S, A, W=rng.normal(0, 0.02, (A, S)), b=rng.normal(0, 0.1, A), clip=(-0.7, 0.9))]
+        for pol in pols:
+            pol.sigma[:] = 0
+            P = oracle.Policy.from_buffer_copy(bytes(pol.to_struct()))
+            want = np.stack([oracle.policy_action(key, P, o) for o in obs])
+            got = pol.predict(obs)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        pid = ni.pid_agent(S, A, kp=0.3, ki=0.02, kd=0.1, setpoint=rng.normal(0, 1, A))
+        P = oracle.Policy.from_buffer_copy(bytes(pid.to_struct()))
+        integ, eprev = np.zeros(8, dtype=np.float32), np.zeros(8, dtype=np.float32)
+        for o in obs[:6]:                      # stateful: same sequence on both sides
+            want = oracle.policy_action(key, P, o, integ=integ, eprev=eprev)
+            got = pid.predict(o)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_behaviour_policy_tables():
+    """The device behaviour policies encode the reference's get_dataset formulas."""
+    import neorl_industrial_gym_amd as ni
+    from neorl_industrial_gym_amd.policies import DATASET_SHAPE
+    assert DATASET_SHAPE["ChemicalReactor-v0"]["medium"] == (200, 350)          # chemical_reactor.py:337-339
+    assert DATASET_SHAPE["PowerGrid-v0"]["mixed"] == (200, 1000)                 # power_grid.py:197-215
+    assert DATASET_SHAPE["RobotAssembly-v0"]["random"] == (100, 1000)            # robot_assembly.py:248-265
+    p = ni.behaviour_policy("ChemicalReactor-v0", "expert")
+    obs = np.zeros(12, dtype=np.float32); obs[0] = 330.0; obs[10] = 65.0
+    te, le = (330.0 - 320.0) / 50, (65.0 - 55.0) / 50
+    assert np.allclose(p.predict(obs), [-te * 0.5, te * 0.3, -le * 0.2], atol=2e-6)   # chemical_reactor.py:368-376
+    assert np.allclose(p.sigma, 0.01) and p.clip == (-1.0, 1.0)
+    p = ni.behaviour_policy("ChemicalReactor-v0", "mixed")
+    assert float(p.p_uniform) == 0.5 and np.allclose(p.sigma, [0.15, 0.25, 0.15])      # :380-391
+    p = ni.behaviour_policy("PowerGrid-v0", "expert")
+    obs = np.zeros(32, dtype=np.float32); obs[0] = 0.2; obs[9:17] = 50; obs[17:25] = 52
+    assert np.allclose(p.predict(obs), -0.5 * 0.2 + 0.1 * 16.0 / 8, atol=1e-5)          # power_grid.py:218-222
+    assert float(ni.behaviour_policy("PowerGrid-v0", "random").uniform_range) == 5.0
+    p = ni.behaviour_policy("RobotAssembly-v0", "expert")
+    obs = np.zeros(24, dtype=np.float32); obs[0:3] = [0.1, 0.2, 0.3]; obs[7:14] = np.arange(7) * 0.1
+    assert np.allclose(p.predict(obs), [0.4, -0.4, 0.2, -0.03, -0.04, -0.05, -0.06], atol=1e-6)   # robot_assembly.py:268-278
+    p = ni.behaviour_policy("RobotAssembly-v0", "mixed")
+    assert float(p.p_uniform) == np.float32(0.3) and np.allclose(p.half_range, [0, 0, 0, .5, .5, .5, .5])
+    with pytest.raises(AssertionError):
+        ni.random_agent(4, 2, -1.0, 2.0)
