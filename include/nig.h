@@ -39,7 +39,11 @@ extern "C" {
 #define NIG_ENV_CHEMICAL_REACTOR 0   /* 'ChemicalReactor-v0'  environments/chemical_reactor.py */
 #define NIG_ENV_POWER_GRID 1         /* 'PowerGrid-v0'        environments/power_grid.py       */
 #define NIG_ENV_ROBOT_ASSEMBLY 2     /* 'RobotAssembly-v0'    environments/robot_assembly.py   */
-#define NIG_NUM_ENVS 3
+/* Candidate rows: registered upstream (utils.py:30-31) but NOT instantiable there;
+ * restated from the source text, no reference output exists to pin them. */
+#define NIG_ENV_ADV_CHEMICAL_REACTOR 3   /* 'AdvancedChemicalReactor-v0'  environments/advanced_chemical_reactor.py */
+#define NIG_ENV_ADV_POWER_GRID 4         /* 'AdvancedPowerGrid-v0'        environments/advanced_power_grid.py       */
+#define NIG_NUM_ENVS 5
 
 /* nig_create flags */
 #define NIG_F_AUTORESET 0x1u   /* finished lanes re-sample their initial state inside the step kernel   */
@@ -55,6 +59,8 @@ extern "C" {
 #define NIG_FLAG_SHUTDOWN 0x200u        /* info['critical_shutdown'], base.py:210            */
 #define NIG_FLAG_DID_RESET 0x400u       /* lane auto-reset in this call (state = new episode)*/
 #define NIG_FLAG_INACTIVE 0x800u        /* lane was already done (no auto-reset): untouched  */
+#define NIG_FLAG_VIOL3 0x1000u          /* 4th safety condition violated (Advanced envs)     */
+#define NIG_FLAG_NVIOL_HI 0x2000u       /* adds 4 to the violation count field (Advanced envs) */
 #define NIG_FLAG_STEP_SHIFT 16          /* bits 16-31: current_step after this call          */
 
 /* per-lane counter word kept by the library */

@@ -15,7 +15,9 @@ import torch
 from . import _lib
 from .core import SafetyMetrics, make_box
 
-ENV_IDS = {"ChemicalReactor-v0": 0, "PowerGrid-v0": 1, "RobotAssembly-v0": 2}
+ENV_IDS = {"ChemicalReactor-v0": 0, "PowerGrid-v0": 1, "RobotAssembly-v0": 2,
+           # candidate rows: registered upstream (utils.py:30-31) but not instantiable there
+           "AdvancedChemicalReactor-v0": 3, "AdvancedPowerGrid-v0": 4}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -30,8 +32,9 @@ class StepInfo:
       constraint_violated [3,B], did_reset, inactive, step.
     """
 
-    def __init__(self, flags: torch.Tensor):
+    def __init__(self, flags: torch.Tensor, n_constraints: int = 3):
         self.flags = flags
+        self.n_constraints = n_constraints
 
     @property
     def terminated(self):
@@ -47,7 +50,7 @@ class StepInfo:
 
     @property
     def violation_count(self):
-        return (self.flags >> _lib.FLAG_NVIOL_SHIFT) & 3
+        return ((self.flags >> _lib.FLAG_NVIOL_SHIFT) & 3) + ((self.flags >> 13) & 1) * 4
 
     @property
     def critical_violations(self):
@@ -59,7 +62,8 @@ class StepInfo:
 
     @property
     def constraint_violated(self):
-        return torch.stack([((self.flags >> (_lib.FLAG_VIOL_SHIFT + k)) & 1) != 0 for k in range(3)])
+        return torch.stack([((self.flags >> (_lib.FLAG_VIOL_SHIFT + k)) & 1) != 0 for k in range(3)]
+                           + [((self.flags >> 12) & 1) != 0])[:self.n_constraints]
 
     @property
     def did_reset(self):
@@ -76,10 +80,11 @@ class StepInfo:
     def safety_metrics(self, lane: int) -> SafetyMetrics:
         """The reference's per-step SafetyMetrics object for one lane (base.py:118-124)."""
         f = int(self.flags[lane].item())
-        nv = (f >> _lib.FLAG_NVIOL_SHIFT) & 3
+        nv = ((f >> _lib.FLAG_NVIOL_SHIFT) & 3) + ((f >> 13) & 1) * 4
         nc = (f >> _lib.FLAG_NCRIT_SHIFT) & 3
-        return SafetyMetrics(constraints_satisfied=3 - nv, total_constraints=3, violation_count=nv,
-                             critical_violations=nc, safety_score=(3 - nv) / 3)
+        n = self.n_constraints
+        return SafetyMetrics(constraints_satisfied=n - nv, total_constraints=n, violation_count=nv,
+                             critical_violations=nc, safety_score=(n - nv) / n)
 
 
 class BatchedIndustrialEnv:
@@ -268,7 +273,7 @@ class BatchedIndustrialEnv:
             _lib.check(self._L.nig_step(self._h, _ptr(act), ld_act, _ptr(sn), _ptr(rn), B,
                                         _ptr(self.reward), _ptr(self.reward64), _ptr(self.flags),
                                         _ptr(final_obs), ld_obs, self._stream()))
-        info = StepInfo(self.flags)
+        info = StepInfo(self.flags, int(self.spec.n_constraints))
         return self.obs, self.reward, info.terminated, info.truncated, info
 
     def step_raw(self, act_soa: torch.Tensor, ld_act: int, reward=True, reward64=False, flags=True):

@@ -43,7 +43,7 @@ __device__ __forceinline__ float det_expf(float x)
     return res;
 }
 
-// ln(x) for a normal float in (0,1] (argument is always k*2^-24, k >= 1).
+// ln(x) for a positive normal float (Box-Muller passes k*2^-24, k >= 1; det_powf any x > 0).
 __device__ __forceinline__ float det_logf(float x)
 {
     const uint32_t u = f32_bits(x);
@@ -97,6 +97,50 @@ __device__ __forceinline__ void det_sincos2pi_u24(uint32_t k, float &s, float &c
     ss = (oct & 4u) ? -ss : ss;
     cc = ((oct + 2u) & 4u) ? -cc : cc;
     s = ss; c = cc;
+}
+
+
+// x^y for x >= 0 (x == 0 -> 0): exp(y * ln x) with the polynomials above.  Stands in for jnp's
+// float32 power in the two Advanced envs (advanced_chemical_reactor.py:301 Re**0.8,
+// advanced_power_grid.py:317 V**alpha); a few ulp, like XLA's own expansion.
+__device__ __forceinline__ float det_powf(float x, float y)
+{
+    const float r = det_expf(y * det_logf(x));
+    return (x > 0.0f) ? r : 0.0f;
+}
+
+// tanh(x) = (1 - e^-2x) / (1 + e^-2x) for x >= 0 (odd extension).  jnp.tanh, advanced_chemical_reactor.py:299
+__device__ __forceinline__ float det_tanhf(float x)
+{
+    const float ax = fabsf(x);
+    const float e = det_expf(-2.0f * ax);
+    const float t = (1.0f - e) / (1.0f + e);
+    return (x < 0.0f) ? -t : t;
+}
+
+// float32 sine, |x| up to a few hundred: Cody-Waite by pi/2 (3 constants), degree-7/8 kernels.
+// jnp.sin of a bus-angle difference, advanced_power_grid.py:402
+__device__ __forceinline__ float det_sinf(float x)
+{
+    const float fk = floorf(x * 0.636619772367581343f + 0.5f);
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float sp = -1.9515295891e-4f;
+    sp = sp * z + 8.3321608736e-3f;
+    sp = sp * z + -1.6666654611e-1f;
+    sp = sp * z * r + r;
+    float cp = 2.443315711809948e-5f;
+    cp = cp * z + -1.388731625493765e-3f;
+    cp = cp * z + 4.166664568298827e-2f;
+    cp = cp * z * z;
+    cp = cp + -0.5f * z;
+    cp = cp + 1.0f;
+    const int q = (int)fk & 3;
+    float v = (q & 1) ? cp : sp;
+    v = (q & 2) ? -v : v;
+    return v;
 }
 
 // double sin/cos for joint angles (|x| small multiples of pi): Cody-Waite with a 33-bit

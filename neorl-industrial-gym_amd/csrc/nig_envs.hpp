@@ -31,7 +31,10 @@ __device__ __forceinline__ T sum8(const T (&x)[8])
 struct ChemicalReactor {
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
+    static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
+    __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
+    __device__ static constexpr float act_high(int) { return 1.0f; }
 
     // chemical_reactor.py:38-60 (penalty, critical) in list order
     __device__ static constexpr float penalty(int k) { return k == 0 ? -100.0f : (k == 1 ? -50.0f : -25.0f); }
@@ -137,7 +140,10 @@ struct ChemicalReactor {
 struct PowerGrid {
     static constexpr int ID = 1, S = 32, A = 8, KS = 23, KR = 31, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~18 % of lanes finish per step (episodes of ~6 steps)
+    static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     using reward_t = double;  // float(total_reward), :177
+    __device__ static constexpr float act_low(int) { return -1.0f; }
+    __device__ static constexpr float act_high(int) { return 1.0f; }
 
     __device__ static constexpr double penalty(int k) { return k == 0 ? -50.0 : (k == 1 ? -30.0 : -20.0); }  // :53-72
     static constexpr uint32_t CRIT_MASK = 0x3u;
@@ -271,7 +277,10 @@ struct PowerGrid {
 struct RobotAssembly {
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
+    static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     using reward_t = double;
+    __device__ static constexpr float act_low(int) { return -1.0f; }
+    __device__ static constexpr float act_high(int) { return 1.0f; }
 
     __device__ static constexpr double penalty(int k) { return k == 0 ? -100.0 : (k == 1 ? -200.0 : -50.0); }  // :56-75
     static constexpr uint32_t CRIT_MASK = 0x3u;
@@ -393,6 +402,241 @@ struct RobotAssembly {
         const bool inside = ((double)n[0] >= -0.6) && ((double)n[0] <= 0.6) && ((double)n[1] >= -0.6) &&
                             ((double)n[1] <= 0.6) && ((double)n[2] >= -0.1) && ((double)n[2] <= 0.9);   // :239-242
         return d || !inside;
+    }
+};
+
+
+// Result of one IndustrialEnv.step for one lane (filled by step_core or by an env's own step).
+template <class Env>
+struct StepResult {
+    typename Env::reward_t reward;
+    uint32_t viol_bits;        // bit k: constraint k violated (up to 4)
+    int nviol, ncrit;
+    bool terminated, truncated, shutdown;
+};
+
+// =================================================================================
+// AdvancedChemicalReactor-v0  (environments/advanced_chemical_reactor.py), S=20 A=6
+//
+// CANDIDATE ROW: upstream this class cannot be instantiated (abstract hooks
+// missing, non-existent SafetyConstraint/SafetyMetrics kwargs, :90-105,445-450) and its step
+// reads an attribute that is never set (self.episode_step, :351,364), so there is NO reference
+// output to pin.  Restated from the source text as the float32 evaluation JAX would do with
+// weak Python scalars (x64 off): Python-only sub-expressions are folded in double first, every
+// op that touches an array value is float32, left to right.  exp / tanh / pow are the detmath
+// polynomials (XLA's own expansions are not correctly rounded either).  The class overrides
+// step(): no action clip, no base constraint loop, no -1000 critical shutdown.
+// episode_step is taken as 0 at reset (the evident intent); dt is the BASE default 0.1, because
+// IndustrialEnv.__init__ (base.py:44) overwrites the 1.0 assigned at :65 before it.
+// =================================================================================
+struct AdvancedChemicalReactor {
+    static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
+    static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    using reward_t = float;    // float(total_reward) of a float32 scalar, :404
+    static constexpr uint32_t CRIT_MASK = 0u;
+    __device__ static constexpr float penalty(int) { return 0.0f; }
+    __device__ static constexpr float act_low(int j) { return j == 3 ? 273.15f : 0.0f; }                  // :148-155
+    __device__ static constexpr float act_high(int j) { return j < 2 ? 0.01f : j == 2 ? 3000.0f : j == 3 ? 473.15f : j == 4 ? 100.0f : 1.0f; }
+
+    __device__ static void init(const double (&)[1], float (&s)[S])       // reset, :158-193
+    {
+        s[0] = 323.15f; s[1] = 313.15f; s[2] = 2e5f; s[3] = 2.0f; s[4] = 1.5f; s[5] = 0.1f; s[6] = 0.1f;
+        s[7] = 0.001f; s[8] = 0.001f; s[9] = 0.005f; s[10] = 300.0f; s[11] = 0.8f;
+        s[12] = 323.15f; s[13] = 323.15f; s[14] = 323.15f; s[15] = 323.15f;
+        s[16] = 1000.0f; s[17] = 0.05f; s[18] = 50.0f; s[19] = 60.0f;
+    }
+    __device__ static void draw_init(const RngKey &, double (&)[1]) {}
+    __device__ static void draw_step(const RngKey &, double (&)[1]) {}
+
+    // step :195-366, _compute_reward :368-404, _check_termination :406-420, get_safety_metrics :422-450
+    __device__ static void custom_step(const float (&s)[S], const float (&a)[A], int step_pre, int max_steps,
+                                       float dt, float (&o)[S], StepResult<AdvancedChemicalReactor> &out)
+    {
+        const float T = s[0], Tj = s[1], cA = s[3], cB = s[4], cC = s[5], cD = s[6];
+        const float Ff = s[7], Fp = s[8], Fc = s[9], hc = s[10], mix = s[11];
+        const bool estop = a[5] > 0.5f;                                  // :219
+        const float feed_a = estop ? 0.0f : a[0];
+        const float cool_a = estop ? 0.01f : a[1];                       // self.flow_range[1]
+        const float rpm = estop ? 0.0f : a[2];
+        const float nFf = Ff + 0.1f * (feed_a - Ff);                     // :226
+        const float nFc = Fc + 0.2f * (cool_a - Fc);                     // :227
+        const float k = 1e8f * det_expf(-83140.0f / (8.314f * T));       // :230
+        const float rr = ((k * cA) * cB) * mix;                          // :231
+        const float dA = ((nFf * 5.0f - Fp * cA) / 1.0f) - rr;           // :234
+        const float dB = ((nFf * 3.0f - Fp * cB) / 1.0f) - rr;           // :235
+        const float dC = (((-Fp) * cC) / 1.0f) + rr;                     // :236
+        const float dD = (((-Fp) * cD) / 1.0f) + rr;                     // :237
+        const float Qgen = (50000.0f * rr) * 1.0f;                       // :240
+        const float Qj = (hc * 4.835975862049409f) * (T - Tj);           // :243 jacket_area :78
+        float Qw = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Qw = Qw + 6044.969827561761f * (T - s[12 + i]);   // :246-250
+        const float Qf = ((nFf * 1000.0f) * 4180.0f) * (a[3] - T);       // :253
+        const float dTr = (((Qgen - Qj) - Qw) + Qf) / 4180000.0f;        // :256-259
+        const float dTj = (Qj - ((nFc * 1000.0f) * 4180.0f) * (Tj - 293.15f)) / 418000.0f;   // :262-266
+        float nTw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                    // :269-280
+            const float w = s[12 + i];
+            const float wd = (5000.0f * (T - w) - 10.0f * (w - 293.15f)) / 25000.0f;
+            nTw[i] = w + dt * wd;
+        }
+        const float moles = (((cA + cB) + cC) + cD) * 1.0f;              // :284
+        const float vp = 1000.0f * det_expf(20.0f - 5000.0f / T);        // :287
+        float nP = ((((8.314f * T) * moles) / 1.0f) + vp) + 1e5f;        // :290-292
+        if (nP > 2400000.0f) nP = nP - (a[4] / 100.0f) * (nP - 2400000.0f);   // :295-297 (3e6*0.8)
+        const float nmix = det_tanhf(rpm / 1000.0f) * 0.9f + 0.1f;       // :300
+        const float Re = ((rpm * 0.1f) * 1000.0f) / 0.001f;              // :301
+        const float Nu = 0.023f * det_powf(Re, 0.8f);                    // :302
+        const float nhc = (Nu * 0.6f) / 0.1f;                            // :303
+        const float nFp = 0.001f * (1.0f + 0.5f * ((nP - 1e5f) / 1e5f)); // :306-307
+        const float nA = fmaxf(0.0f, cA + dt * dA), nB = fmaxf(0.0f, cB + dt * dB);   // :310-313
+        const float nC = fmaxf(0.0f, cC + dt * dC), nD = fmaxf(0.0f, cD + dt * dD);
+        const float nT = T + dt * dTr, nTj = Tj + dt * dTj;              // :315-316
+        const float tau = 1.0f / fmaxf(nFp, 1e-6f);                      // :319
+        const float conv = (2.0f - nA) / 2.0f;                           // :322-323
+        const float mT = ((673.15f - nT) / 673.15f) * 100.0f;            // :326
+        const float mP = ((5e6f - nP) / 5e6f) * 100.0f;                  // :327
+        o[0] = nT; o[1] = nTj; o[2] = nP; o[3] = nA; o[4] = nB; o[5] = nC; o[6] = nD;
+        o[7] = nFf; o[8] = nFp; o[9] = nFc; o[10] = nhc; o[11] = nmix;
+        o[12] = nTw[0]; o[13] = nTw[1]; o[14] = nTw[2]; o[15] = nTw[3];
+        o[16] = tau; o[17] = conv; o[18] = mT; o[19] = mP;
+        // reward on the new state
+        const float pr = 100.0f * (nC / 5.0f + conv);                    // :379
+        const float sr = (mT + mP) / 2.0f;                               // :382
+        const float te = 1.0f - fabsf(nT - 373.15f) / 100.0f;            // :385
+        const float pe = 1.0f - fabsf(nP - 3e5f) / 1e5f;                 // :386
+        const float er = 50.0f * (te + pe);                              // :388
+        const float cp = (-((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4]))) * 10.0f;   // :391
+        const float ep = estop ? -1000.0f : 0.0f;                        // :394
+        out.reward = (((pr + sr) + er) + cp) + ep;                       // :396-402
+        out.viol_bits = ((nT > 673.15f) ? 1u : 0u) | ((nP > 5e6f) ? 2u : 0u) |          // :433-443
+                        ((mT < 10.0f) ? 4u : 0u) | ((mP < 10.0f) ? 8u : 0u);
+        out.nviol = __popc(out.viol_bits); out.ncrit = 0;
+        out.terminated = (nT > 673.15f) || (nP > 5e6f) || (nC > 8.0f);   // :412-420
+        out.truncated = step_pre >= max_steps;                           // :351 (episode_step before its increment)
+        out.shutdown = estop;                                            // info['emergency_shutdown'], :359
+    }
+};
+
+// =================================================================================
+// AdvancedPowerGrid-v0  (environments/advanced_power_grid.py), S=32 A=8
+// CANDIDATE ROW: same status as above (not instantiable upstream; :101-121,
+// 532-537; self.episode_step :331,345 never set).  State layout as actually built at :217-224.
+// =================================================================================
+struct AdvancedPowerGrid {
+    static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
+    static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    using reward_t = float;
+    static constexpr uint32_t CRIT_MASK = 0u;
+    __device__ static constexpr float penalty(int) { return 0.0f; }
+    __device__ static constexpr float H(int i) { return i == 0 ? 5.0f : i == 1 ? 4.0f : i == 2 ? 3.5f : 4.5f; }      // :79-85
+    __device__ static constexpr float D(int i) { return i == 0 ? 1.0f : i == 1 ? 0.8f : i == 2 ? 0.9f : 1.1f; }
+    __device__ static constexpr float Pmax(int i) { return i == 0 ? 50.0f : i == 1 ? 40.0f : i == 2 ? 35.0f : 45.0f; }
+    __device__ static constexpr float Pmin(int i) { return i == 0 ? 10.0f : i == 1 ? 8.0f : i == 2 ? 7.0f : 9.0f; }
+    __device__ static constexpr float ramp(int i) { return i == 0 ? 2.0f : i == 1 ? 1.8f : i == 2 ? 1.5f : 2.2f; }
+    __device__ static constexpr float base_load(int i) { return i == 0 ? 25.0f : i == 1 ? 20.0f : i == 2 ? 30.0f : 18.0f; }   // :93-97
+    __device__ static constexpr float alpha(int i) { return i == 0 ? 1.5f : i == 1 ? 1.2f : i == 2 ? 1.8f : 1.3f; }
+    __device__ static constexpr float Kf(int i) { return i == 0 ? 1.0f : i == 1 ? 0.8f : i == 2 ? 1.2f : 0.9f; }
+    __device__ static constexpr float act_low(int j) { return j < 4 ? Pmin(j) : j < 6 ? 0.95f : 0.0f; }               // :163-178
+    __device__ static constexpr float act_high(int j) { return j < 4 ? Pmax(j) : j < 6 ? 1.05f : j == 6 ? 20.0f : 1.0f; }
+
+    __device__ static void init(const double (&)[1], float (&s)[S])       // reset, :182-226
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 1.0f;
+        s[8] = 0.0f; s[9] = -0.1f; s[10] = 0.05f; s[11] = -0.05f; s[12] = 0.02f; s[13] = -0.02f; s[14] = 0.08f; s[15] = -0.08f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[16 + i] = 50.0f; s[24 + i] = base_load(i); }
+        s[20] = 30.0f; s[21] = 25.0f; s[22] = 20.0f; s[23] = 28.0f;
+        s[28] = 15.0f; s[29] = -12.0f; s[30] = 18.0f; s[31] = -14.0f;
+    }
+    __device__ static void draw_init(const RngKey &, double (&)[1]) {}
+    __device__ static void draw_step(const RngKey &, double (&)[1]) {}
+
+    // step :228-354, _solve_power_flow :356-407, _calculate_stability_margin :409-434,
+    // _compute_reward :436-482, _check_termination :484-501, get_safety_metrics :503-537
+    __device__ static void custom_step(const float (&s)[S], const float (&a)[A], int step_pre, int max_steps,
+                                       float dt, float (&o)[S], StepResult<AdvancedPowerGrid> &out)
+    {
+        const bool emerg = a[7] > 0.5f;                                  // :246
+        float sp[4], nf[4], nPg[4], nL[4];
+        const float shed = emerg ? fminf(a[6] + 10.0f, 30.0f) : a[6];    // :249
+        float fsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sp[i] = emerg ? a[i] * 0.7f : a[i];                          // :248
+            const float pm = sp[i] / 100.0f, pe = s[20 + i] / 100.0f;    // :261-262
+            const float df = ((pm - pe) - D(i) * (s[16 + i] - 50.0f)) / (2.0f * H(i));   // :264-265
+            nf[i] = s[16 + i] + dt * df;                                 // :272
+            fsum = fsum + nf[i] * H(i);                                  // :276
+        }
+        const float fsys = fsum / 17.0f;                                 // :275-276 (sum of inertias)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                    // :279-289
+            const float mr = ramp(i) * dt;
+            float ch = sp[i] - s[20 + i];
+            ch = fminf(fmaxf(ch, -mr), mr);
+            nPg[i] = fminf(fmaxf(s[20 + i] + ch, Pmin(i)), Pmax(i));
+        }
+        const float fdev = (fsys - 50.0f) / 50.0f;                       // :304
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                    // :293-308
+            float bl = base_load(i);
+            if (i == 0) bl = fmaxf(bl - shed, 0.0f);
+            const float ve = det_powf(s[i] / 1.0f, alpha(i));
+            const float fe = 1.0f + Kf(i) * fdev;
+            nL[i] = (bl * ve) * fe;
+        }
+        float nV[8], nTh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                                    // :368-389
+            const float inj = (i < 4) ? nPg[i] / 100.0f : (-nL[i - 4]) / 100.0f;
+            float v = s[i] + 0.01f * inj;
+            if (i == 0) v = a[4];
+            if (i == 1) v = a[5];
+            nV[i] = fminf(fmaxf(v, 0.8f), 1.2f);
+            nTh[i] = s[8 + i] + 0.05f * inj;
+        }
+        float flow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                                      // :395-405
+            flow[i] = (((nV[i] * nV[i + 4]) / 0.1f) * det_sinf(nTh[i] - nTh[i + 4])) * 100.0f;
+        float vmax = 0.0f, vmean = 0.0f, thmax = nTh[0], thmin = nTh[0], fmax_dev = 0.0f;
+        bool vviol = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dv = fabsf(nV[i] - 1.0f);
+            vmax = fmaxf(vmax, dv); vmean = vmean + dv;
+            vviol = vviol || (dv > 0.05f);
+            thmax = fmaxf(thmax, nTh[i]); thmin = fminf(thmin, nTh[i]);
+        }
+        vmean = vmean / 8.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fmax_dev = fmaxf(fmax_dev, fabsf(nf[i] - 50.0f));
+        const float stab = fmaxf(fminf(fminf(1.0f - vmax, 1.0f - (thmax - thmin) / 3.14159265358979323846f),
+                                       1.0f - fmax_dev / 0.5f), 0.0f);  // :417-434
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o[i] = nV[i]; o[8 + i] = nTh[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[16 + i] = nf[i]; o[20 + i] = nPg[i]; o[24 + i] = nL[i]; o[28 + i] = flow[i]; }
+        // reward :436-482
+        const float ferr = fabsf(fsys - 50.0f);
+        const float r_f = 100.0f * det_expf((-ferr) / 0.1f);
+        const float r_v = 50.0f * det_expf((-vmean) / 0.05f);
+        const float tg = ((nPg[0] + nPg[1]) + nPg[2]) + nPg[3], tl = ((nL[0] + nL[1]) + nL[2]) + nL[3];
+        const float r_b = 30.0f * det_expf((-fabsf(tg - tl)) / 10.0f);
+        const float r_e = -(0.01f * ((((nPg[0] * nPg[0]) + (nPg[1] * nPg[1])) + (nPg[2] * nPg[2])) + (nPg[3] * nPg[3])));
+        const float r_c = (-(((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4])) + fabsf(a[5]))) * 1.0f;
+        out.reward = (((((r_f + r_v) + r_b) + r_e) + r_c) + (-a[6]) * 50.0f) + (-a[7]) * 200.0f;
+        bool glim = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glim = glim || (nPg[i] < Pmin(i)) || (nPg[i] > Pmax(i));   // :521-523
+        out.viol_bits = ((ferr > 0.5f) ? 1u : 0u) | (vviol ? 2u : 0u) | (glim ? 4u : 0u);      // :511-523
+        out.nviol = __popc(out.viol_bits); out.ncrit = 0;
+        out.terminated = (ferr > 0.5f) || vviol || (stab < 0.1f);        // :492-501
+        out.truncated = step_pre >= max_steps;                           // :331
+        out.shutdown = emerg;                                            // info['emergency_active'], :341
     }
 };
 

@@ -40,14 +40,6 @@ struct StepArgs {
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
 };
 
-template <class Env>
-struct StepResult {
-    typename Env::reward_t reward;
-    uint32_t viol_bits;
-    int nviol, ncrit;
-    bool terminated, truncated;
-};
-
 // IndustrialEnv.step for one lane, entirely in registers (base.py:157-213).
 template <class Env>
 __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[Env::A],
@@ -56,6 +48,12 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
                                           float (&n)[Env::S], StepResult<Env> &out)
 {
     using R = typename Env::reward_t;
+    if constexpr (Env::CUSTOM_STEP) {             // the Advanced envs override step() wholesale
+        Env::custom_step(s, a, step_pre, max_steps, dt32, n, out);
+        out.viol_bits &= cmask;
+        out.nviol = __popc(out.viol_bits);
+        return;
+    } else {
 #pragma unroll
     for (int k = 0; k < Env::A; ++k) {            // base.py:167 np.clip(action, -1, 1) == min(max(x,lo),hi)
         float x = a[k];
@@ -75,7 +73,19 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
     const bool trunc = (step_pre + 1) >= max_steps;   // base.py:191
     if (ncrit > 0) { term = true; r = r - (R)1000; }  // base.py:195-198
     out.reward = r; out.viol_bits = vb; out.nviol = nviol; out.ncrit = ncrit;
-    out.terminated = term; out.truncated = trunc;
+    out.terminated = term; out.truncated = trunc; out.shutdown = ncrit > 0;   // info['critical_shutdown'], base.py:210
+    }
+}
+
+// The per-lane flag word of one step (include/nig.h NIG_FLAG_*).
+template <class Env>
+__device__ __forceinline__ uint32_t pack_flags(const StepResult<Env> &res, int step)
+{
+    return (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
+           ((res.viol_bits & 7u) << NIG_FLAG_VIOL_SHIFT) | ((res.viol_bits & 8u) ? NIG_FLAG_VIOL3 : 0u) |
+           (((uint32_t)res.nviol & 3u) << NIG_FLAG_NVIOL_SHIFT) | (((uint32_t)res.nviol & 4u) ? NIG_FLAG_NVIOL_HI : 0u) |
+           ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.shutdown ? NIG_FLAG_SHUTDOWN : 0u) |
+           ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
 }
 
 // Per-lane key of the counter-based generator: (global env index, launch counter t).
@@ -170,7 +180,6 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     constexpr int NWAVE = BLOCK / 64;
-    using R = typename Env::reward_t;
     __shared__ unsigned short s_list[BLOCK];
     __shared__ int s_cnt[NWAVE];
 
@@ -224,10 +233,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
     const int step = step_pre + 1;
     const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;   // base.py:182
     const bool done = res.terminated || res.truncated;
-    uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
-                  (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
-                  ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
-                  ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
+    uint32_t fl = pack_flags<Env>(res, step);
     uint32_t nctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
     const bool need_reset = active && done && autoreset;
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
         double ret = 0.0;
         if (p.tally) {                            // utils.py:99  episode_return += reward
             const double prev = (p.ep_ret + base)[tid];
-            if constexpr (sizeof(R) == 4) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR)
+            if constexpr (Env::RET_F32) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR)
             else ret = prev + (double)res.reward;
         }
         if (done) {
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
 #pragma unroll
         for (int q = 0; q < NWAVE - 1; ++q) { const bool nxt = (w == q) && (r >= cnt[q]); r = nxt ? r - cnt[q] : r; w = nxt ? q + 1 : w; }
         const unsigned tl = s_list[w * 64 + r];   // block-local index of the lane being reset
-        double rn[KR];
+        double rn[KR > 0 ? KR : 1];
         if constexpr (PARITY) {
             const double *rn_row = p.reset_noise + base;
 #pragma unroll
@@ -392,10 +398,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
         const bool done = (res.terminated || res.truncated) && !frozen;
-        uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
-                      (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
-                      ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
-                      ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
+        uint32_t fl = pack_flags<Env>(res, step);
         float rew = (float)res.reward;
         if (frozen) {                              // untouched lane: discard the speculative step
             fl = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         } else {
             ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
             if (tally) {
-                if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
+                if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
                 else ret = ret + (double)res.reward;
             }
         }
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         }
         if constexpr (!COMPACT) {
             if (done && autoreset) {               // divergent per-lane reset (base.py:133-155)
-                double rn[KR];
+                double rn[KR > 0 ? KR : 1];
                 Env::draw_init(key, rn);
                 Env::init(rn, n);
                 ctr = 0u;
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
 #pragma unroll
                 for (int qq = 0; qq < NWAVE - 1; ++qq) { const bool nxt = (w == qq) && (r >= cnt[qq]); r = nxt ? r - cnt[qq] : r; w = nxt ? qq + 1 : w; }
                 const unsigned tl = s_list[w * 64 + r];
-                double rn[KR];
+                double rn[KR > 0 ? KR : 1];
                 Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi), rn);
                 float r0[S];
                 Env::init(rn, r0);
@@ -638,13 +641,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
         const bool done = res.terminated || res.truncated;
-        uint32_t fl = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
-                      (res.viol_bits << NIG_FLAG_VIOL_SHIFT) | ((uint32_t)res.nviol << NIG_FLAG_NVIOL_SHIFT) |
-                      ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.ncrit > 0 ? NIG_FLAG_SHUTDOWN : 0u) |
-                      ((uint32_t)step << NIG_FLAG_STEP_SHIFT) | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
+        uint32_t fl = pack_flags<Env>(res, step) | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
         ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
         if (tally) {
-            if constexpr (sizeof(R) == 4) ret = (double)((float)ret + res.reward);
+            if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
             else ret = ret + (double)res.reward;
         }
         if (p.reward) (p.reward + base + orow)[tid] = (float)res.reward;
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
             lt.life += (long long)viol_ep;
             if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
             if (autoreset) {
-                double rn[KR];
+                double rn[KR > 0 ? KR : 1];
                 Env::draw_init(key, rn);
                 Env::init(rn, n);
                 ctr = 0u;
@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(BLOCK) reset_kernel(const ResetArgs p)
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= p.B) return;
     if (p.mask && !p.mask[i]) return;
-    double rn[KR];
+    double rn[KR > 0 ? KR : 1];
     if constexpr (PARITY) {
 #pragma unroll
         for (int k = 0; k < KR; ++k) rn[k] = p.noise[(int64_t)k * p.ld_noise + i];
@@ -716,7 +716,8 @@ __global__ void __launch_bounds__(BLOCK) fill_actions_kernel(float *act, int64_t
     double u[Env::A];
     gen_uniforms<Env::A>(key, STREAM_ACTION, u);
 #pragma unroll
-    for (int k = 0; k < Env::A; ++k) act[(int64_t)k * ld_act + i] = (float)(2.0 * u[k] - 1.0);
+    for (int k = 0; k < Env::A; ++k)      // uniform in the env's action Box: low + (high - low) * u
+        act[(int64_t)k * ld_act + i] = (float)((double)Env::act_low(k) + ((double)Env::act_high(k) - (double)Env::act_low(k)) * u[k]);
 }
 
 __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long *life, double *ep_ret, double *tally,
@@ -853,8 +854,22 @@ static const nig_env_spec SPECS[NIG_NUM_ENVS] = {
     {12, 3, 3, 500, 2, 8, 0.1, {-100.0, -50.0, -25.0}, {1, 1, 0}, 1},
     {32, 8, 3, 1000, 23, 31, 0.1, {-50.0, -30.0, -20.0}, {1, 1, 0}, 0},
     {24, 7, 3, 1000, 0, 7, 0.1, {-100.0, -200.0, -50.0}, {1, 1, 0}, 0},
+    /* Advanced envs: 4 / 3 safety-metric conditions, no penalties through the base loop, deterministic */
+    {20, 6, 4, 1000, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
+    {32, 8, 3, 500, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
 };
-static const char *NAMES[NIG_NUM_ENVS] = {"ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0"};
+static const char *NAMES[NIG_NUM_ENVS] = {"ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0",
+                                          "AdvancedChemicalReactor-v0", "AdvancedPowerGrid-v0"};
+
+// run `F<Env>(args...)` for the env type behind a run-time id
+#define NIG_DISPATCH_ENV(env_id, CALL)                                      \
+    switch (env_id) {                                                       \
+    case NIG_ENV_CHEMICAL_REACTOR: { using E = ChemicalReactor; CALL; } break;          \
+    case NIG_ENV_POWER_GRID: { using E = PowerGrid; CALL; } break;                      \
+    case NIG_ENV_ROBOT_ASSEMBLY: { using E = RobotAssembly; CALL; } break;              \
+    case NIG_ENV_ADV_CHEMICAL_REACTOR: { using E = AdvancedChemicalReactor; CALL; } break; \
+    default: { using E = AdvancedPowerGrid; CALL; } break;                  \
+    }
 
 template <class Env>
 static void launch_reset(const ResetArgs &a, bool parity, hipStream_t st)
@@ -883,11 +898,7 @@ static void launch_rollout_env(int out_mode, const RolloutArgs &q, unsigned grid
 
 static void launch_rollout(int env, int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
-    switch (env) {
-    case NIG_ENV_CHEMICAL_REACTOR: launch_rollout_env<ChemicalReactor>(out_mode, q, grid, st); break;
-    case NIG_ENV_POWER_GRID: launch_rollout_env<PowerGrid>(out_mode, q, grid, st); break;
-    default: launch_rollout_env<RobotAssembly>(out_mode, q, grid, st); break;
-    }
+    NIG_DISPATCH_ENV(env, launch_rollout_env<E>(out_mode, q, grid, st));
 }
 
 static StepArgs base_step_args(const nig_handle *h)
@@ -907,11 +918,7 @@ static StepArgs base_step_args(const nig_handle *h)
 
 static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, hipStream_t st)
 {
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR: launch_step<ChemicalReactor>(a, parity, st); break;
-    case NIG_ENV_POWER_GRID: launch_step<PowerGrid>(a, parity, st); break;
-    default: launch_step<RobotAssembly>(a, parity, st); break;
-    }
+    NIG_DISPATCH_ENV(h->env, launch_step<E>(a, parity, st));
 }
 
 extern "C" {
@@ -974,6 +981,8 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     if (max_episode_steps < 0 || max_episode_steps > NIG_MAX_EPISODE_STEPS)
         return fail(NIG_ERR_INVALID, "nig_create: max_episode_steps outside [1, 21845]%s");
     if (dt < 0.0 || dt != dt) return fail(NIG_ERR_INVALID, "nig_create: bad dt%s");
+    if (SPECS[env].n_constraints > 3 && max_episode_steps > 16383)
+        return fail(NIG_ERR_INVALID, "nig_create: max_episode_steps > 16383 for an env with 4 safety conditions%s");
     if (env == NIG_ENV_CHEMICAL_REACTOR && dt != 0.0 && dt != 0.1)
         return fail(NIG_ERR_UNSUPPORTED, "nig_create: ChemicalReactor hard-codes dt=0.1 upstream (chemical_reactor.py:68)%s");
     int ndev = 0;
@@ -989,7 +998,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->env = env; h->device = device; h->B = batch; h->seed = seed; h->env0 = env_index0;
     h->max_steps = max_episode_steps ? max_episode_steps : SPECS[env].max_episode_steps;
     h->dt = (dt != 0.0) ? dt : SPECS[env].dt;
-    h->flags = flags; h->t = 0; h->cmask = 0x7u;
+    h->flags = flags; h->t = 0; h->cmask = 0xFu;
     nig_layout_query(env, batch, flags, &h->lay);
     if (workspace) {
         if (((uintptr_t)workspace & 255u) != 0) { delete h; return fail(NIG_ERR_INVALID, "nig_create: workspace not 256-byte aligned%s"); }
@@ -1059,7 +1068,7 @@ int nig_bind_state(nig_handle *h, float *state, int64_t ld)
 int nig_set_constraint_mask(nig_handle *h, uint32_t mask)
 {
     if (!h) return fail(NIG_ERR_INVALID, "nig_set_constraint_mask: NULL handle%s");
-    h->cmask = mask & 0x7u;
+    h->cmask = mask & 0xFu;
     return NIG_OK;
 }
 
@@ -1082,11 +1091,7 @@ int nig_reset(nig_handle *h, const uint8_t *mask, const double *init_noise, int6
     a.ld = L.ld; a.B = h->B; a.mask = mask; a.noise = init_noise; a.ld_noise = ld_noise;
     a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32); a.t = h->t;
     hipStream_t st = (hipStream_t)stream;
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR: launch_reset<ChemicalReactor>(a, init_noise != nullptr, st); break;
-    case NIG_ENV_POWER_GRID: launch_reset<PowerGrid>(a, init_noise != nullptr, st); break;
-    default: launch_reset<RobotAssembly>(a, init_noise != nullptr, st); break;
-    }
+    NIG_DISPATCH_ENV(h->env, launch_reset<E>(a, init_noise != nullptr, st));
     HIP_TRY(hipGetLastError());
     return NIG_OK;
 }
@@ -1198,11 +1203,7 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
     q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
     q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
     hipStream_t st = (hipStream_t)stream;
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR: hipLaunchKernelGGL((rollout_policy_kernel<ChemicalReactor>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    case NIG_ENV_POWER_GRID: hipLaunchKernelGGL((rollout_policy_kernel<PowerGrid>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    default: hipLaunchKernelGGL((rollout_policy_kernel<RobotAssembly>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q); break;
-    }
+    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_policy_kernel<E>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q));
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;
@@ -1273,17 +1274,7 @@ int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, 
     if (!h || !actions || ld_act < h->B) return fail(NIG_ERR_INVALID, "nig_fill_actions: bad argument%s");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t lo = (uint32_t)h->seed, hi = (uint32_t)(h->seed >> 32);
-    switch (h->env) {
-    case NIG_ENV_CHEMICAL_REACTOR:
-        hipLaunchKernelGGL((fill_actions_kernel<ChemicalReactor>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, actions, ld_act, h->B, h->env0, lo, hi, t);
-        break;
-    case NIG_ENV_POWER_GRID:
-        hipLaunchKernelGGL((fill_actions_kernel<PowerGrid>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, actions, ld_act, h->B, h->env0, lo, hi, t);
-        break;
-    default:
-        hipLaunchKernelGGL((fill_actions_kernel<RobotAssembly>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, actions, ld_act, h->B, h->env0, lo, hi, t);
-        break;
-    }
+    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((fill_actions_kernel<E>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, actions, ld_act, h->B, h->env0, lo, hi, t));
     HIP_TRY(hipGetLastError());
     return NIG_OK;
 }

@@ -25,6 +25,7 @@ class IndustrialEnv:
     """Host mirror of environments/base.py:19-228 (one env instance, B = 1)."""
 
     ENV_ID: str = ""
+    _no_clip = False          # the Advanced envs override step() and never clip
 
     def __init__(self, max_episode_steps: Optional[int] = None, dt: Optional[float] = None,
                  device="cuda:0", noise: str = "numpy", seed: int = 0x5EED):
@@ -107,7 +108,7 @@ class IndustrialEnv:
             raise RuntimeError("Environment is done. Call reset() first.")
         action = np.asarray(action)
         a32 = action.astype(np.float32, copy=False).reshape(self.action_dim)
-        a_clip = np.clip(a32, self.action_space.low, self.action_space.high)       # base.py:167
+        a_clip = a32 if self._no_clip else np.clip(a32, self.action_space.low, self.action_space.high)   # base.py:167
         state_pre = self.state
         mask = self._sync_constraint_mask()
         custom = [c for c in self.safety_constraints if not any(c is b for b in self._builtin)]
@@ -123,7 +124,7 @@ class IndustrialEnv:
         reward64 = float(self._b.reward64.item())
         reward: Any = f32(reward64) if int(self._b.spec.reward_is_f32) else reward64
 
-        nv = (flags >> _lib.FLAG_NVIOL_SHIFT) & 3
+        nv = ((flags >> _lib.FLAG_NVIOL_SHIFT) & 3) + ((flags >> 13) & 1) * 4
         nc = (flags >> _lib.FLAG_NCRIT_SHIFT) & 3
         terminated = bool(flags & _lib.FLAG_TERMINATED)
         truncated = bool(flags & _lib.FLAG_TRUNCATED)
@@ -173,7 +174,7 @@ class IndustrialEnv:
         info = self._get_safety_info(self.state)
         info.update({"step": self.current_step, "violations": self.violation_count,
                      "total_violations": self.total_violations, "safety_metrics": safety_metrics,
-                     "critical_shutdown": crit > 0})
+                     "critical_shutdown": bool(flags & _lib.FLAG_SHUTDOWN) or crit > 0})
         return obs, reward, terminated, truncated, info
 
     def get_safety_metrics(self) -> SafetyMetrics:
@@ -335,3 +336,63 @@ class RobotAssemblyEnv(IndustrialEnv):
 
     def _draw_step_noise(self):    # deterministic step
         return None
+
+
+class _AdvancedEnv(IndustrialEnv):
+    """Shared host glue of the two Advanced envs.  CANDIDATE ROWS: upstream
+    neither class can be instantiated (abstract hooks missing, non-existent dataclass kwargs) and
+    step() reads an attribute nothing sets, so these follow the source text's evident intent:
+    step() overridden wholesale (no action clip, no base constraint loop, no -1000 shutdown),
+    deterministic reset, episode_step = 0 at reset, SafetyMetrics built from the core fields."""
+    _no_clip = True
+    _VIOLATIONS = ()
+
+    def __init__(self, **kwargs):
+        kwargs.setdefault("noise", "device")            # nothing to draw: deterministic
+        super().__init__(**kwargs)
+        from .core import make_box
+        lo, hi = self._ACTION_BOX
+        self.action_space = make_box(np.array(lo, dtype=f32), np.array(hi, dtype=f32), (self.action_dim,), f32)
+
+    def _builtin_constraints(self):
+        return [SafetyConstraint(n, (lambda s, a, _n=n: True), 0.0, False,
+                                 "evaluated on the device; see get_safety_metrics()") for n in self._VIOLATIONS]
+
+    def _draw_reset_noise(self):
+        return np.zeros(0)
+
+    def _draw_step_noise(self):
+        return None
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = super().step(action)
+        fl = int(self._b.flags.item())
+        names = [n for k, n in enumerate(self._VIOLATIONS) if (fl >> (2 + k if k < 3 else 12)) & 1]
+        info["violation_types"] = names
+        info.update(self._extra_info(obs, action, fl))
+        return obs, float(reward), terminated, truncated, info
+
+
+class AdvancedChemicalReactorEnv(_AdvancedEnv):
+    """environments/advanced_chemical_reactor.py (20-D CSTR, 6 actions)."""
+    ENV_ID = "AdvancedChemicalReactor-v0"
+    _ACTION_BOX = ([0.0, 0.0, 0.0, 273.15, 0.0, 0.0], [0.01, 0.01, 3000.0, 473.15, 100.0, 1.0])      # :148-155
+    _VIOLATIONS = ("temperature_limit", "pressure_limit", "temperature_margin", "pressure_margin")    # :433-443
+
+    def _extra_info(self, obs, action, fl):      # info dict of :354-361 (state-derived entries)
+        return {"conversion": float(obs[17]), "residence_time": float(obs[16]),
+                "emergency_shutdown": bool(np.asarray(action)[5] > 0.5),
+                "pressure_relief_active": bool(np.asarray(action)[4] > 0)}
+
+
+class AdvancedPowerGridEnv(_AdvancedEnv):
+    """environments/advanced_power_grid.py (8-bus grid, 4 generators)."""
+    ENV_ID = "AdvancedPowerGrid-v0"
+    _ACTION_BOX = ([10.0, 8.0, 7.0, 9.0, 0.95, 0.95, 0.0, 0.0], [50.0, 40.0, 35.0, 45.0, 1.05, 1.05, 20.0, 1.0])   # :163-178
+    _VIOLATIONS = ("frequency_deviation", "voltage_deviation", "generation_limits")                               # :511-523
+
+    def _extra_info(self, obs, action, fl):      # :334-343
+        H = np.array([5.0, 4.0, 3.5, 4.5], dtype=f32)
+        return {"system_frequency": float(np.sum(obs[16:20] * H) / np.sum(H)),
+                "total_generation": float(np.sum(obs[20:24])), "total_load": float(np.sum(obs[24:28])),
+                "emergency_active": bool(np.asarray(action)[7] > 0.5), "load_shedding_amount": float(np.asarray(action)[6])}

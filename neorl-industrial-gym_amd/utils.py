@@ -6,20 +6,23 @@ import torch
 
 from . import _lib
 from .batched import BatchedIndustrialEnv
-from .envs import ChemicalReactorEnv, PowerGridEnv, RobotAssemblyEnv
+from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalReactorEnv, PowerGridEnv,
+                   RobotAssemblyEnv)
 from .parallel import all_reduce_partial, metrics_from_partial
 
 _REGISTRY = {
     "ChemicalReactor-v0": ChemicalReactorEnv,
     "PowerGrid-v0": PowerGridEnv,
     "RobotAssembly-v0": RobotAssemblyEnv,
+    "AdvancedChemicalReactor-v0": AdvancedChemicalReactorEnv,     # utils.py:30-31: registered upstream but
+    "AdvancedPowerGrid-v0": AdvancedPowerGridEnv,                 # not instantiable there (candidate rows)
 }
 
 
 def make(env_id: str, **kwargs) -> Any:
-    """utils.py:12-39.  Unknown ids raise the reference's ValueError text.  The two
-    'Advanced*' ids of the upstream registry cannot be instantiated upstream either
-    (abstract methods missing, SURVEY.md finding 2) and are not registered here."""
+    """utils.py:12-39.  Unknown ids raise the reference's ValueError text.  The two 'Advanced*'
+    ids are registered as upstream; there they raise TypeError on construction (abstract methods
+    missing, SURVEY.md finding 2), here they are built from the source text (candidate rows)."""
     if env_id not in _REGISTRY:
         available = ", ".join(_REGISTRY.keys())
         raise ValueError(f"Unknown environment '{env_id}'. Available: {available}")

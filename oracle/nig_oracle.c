@@ -26,6 +26,8 @@
 #define ORACLE_CR 0
 #define ORACLE_PG 1
 #define ORACLE_RA 2
+#define ORACLE_ACR 3 /* AdvancedChemicalReactor-v0: candidate row, no upstream output exists (not instantiable) */
+#define ORACLE_APG 4 /* AdvancedPowerGrid-v0: same */
 
 #define MATH_LIBM 0 /* libm expf / sin / cos                    */
 #define MATH_POLY 1 /* documented polynomials (DESIGN.md "detmath"), bitwise = device */
@@ -151,6 +153,39 @@ static void det_sincos(double x, double *s, double *c)
     }
 }
 
+static float det_powf(float x, float y) { return (x > 0.0f) ? det_expf(y * det_logf(x)) : 0.0f; }
+static float det_tanhf(float x)
+{
+    float ax = fabsf(x);
+    float e = det_expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return (x < 0.0f) ? -t : t;
+}
+static float det_sinf(float x)
+{
+    float fk = floorf(x * 0.636619772367581343f + 0.5f);
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    float z = r * r;
+    float sp = -1.9515295891e-4f;
+    sp = sp * z + 8.3321608736e-3f;
+    sp = sp * z + -1.6666654611e-1f;
+    sp = sp * z * r + r;
+    float cp = 2.443315711809948e-5f;
+    cp = cp * z + -1.388731625493765e-3f;
+    cp = cp * z + 4.166664568298827e-2f;
+    cp = cp * z * z;
+    cp = cp + -0.5f * z;
+    cp = cp + 1.0f;
+    int q = (int)fk & 3;
+    float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+}
+static float o_powf(float x, float y, int flavor) { return flavor == MATH_POLY ? det_powf(x, y) : powf(x, y); }
+static float o_tanhf(float x, int flavor) { return flavor == MATH_POLY ? det_tanhf(x) : tanhf(x); }
+static float o_sinf(float x, int flavor) { return flavor == MATH_POLY ? det_sinf(x) : sinf(x); }
+
 static float o_expf(float x, int flavor) { return flavor == MATH_POLY ? det_expf(x) : expf(x); }
 static void o_sincos(double x, int flavor, double *s, double *c)
 {
@@ -182,15 +217,18 @@ typedef struct {
     int critical[3];
 } oracle_spec_t;
 
-static const oracle_spec_t SPECS[3] = {
+static const oracle_spec_t SPECS[5] = {
     /* chemical_reactor.py:38-69 */ {12, 3, 3, 2, 8, 500, 0.1, {-100.0, -50.0, -25.0}, {1, 1, 0}},
     /* power_grid.py:53-79       */ {32, 8, 3, 23, 31, 1000, 0.1, {-50.0, -30.0, -20.0}, {1, 1, 0}},
     /* robot_assembly.py:56-82   */ {24, 7, 3, 0, 7, 1000, 0.1, {-100.0, -200.0, -50.0}, {1, 1, 0}},
+    /* advanced_chemical_reactor.py:50-62,109-115 (dt: base.py:44 overwrites the 1.0 of :65) */
+    {20, 6, 4, 0, 0, 1000, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}},
+    /* advanced_power_grid.py:55-63,124-130 */ {32, 8, 3, 0, 0, 500, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}},
 };
 
 int oracle_spec(int env, oracle_spec_t *out)
 {
-    if (env < 0 || env > 2) return -1;
+    if (env < 0 || env > 4) return -1;
     *out = SPECS[env];
     return 0;
 }
@@ -472,6 +510,165 @@ static void ra_checks(const float *s, const float *a, int *ok)
     ok[0] = f; ok[1] = c; ok[2] = v;
 }
 
+
+/* ------------------------------------------------------------------------------
+ * AdvancedChemicalReactor-v0 / AdvancedPowerGrid-v0 -- CANDIDATE ROWS, PARITY UNPINNED.
+ * Neither class can be instantiated upstream (abstract hooks missing; SafetyConstraint /
+ * SafetyMetrics are given kwargs that do not exist: advanced_chemical_reactor.py:90-105,
+ * 445-450; advanced_power_grid.py:101-121,532-537) and step() reads self.episode_step, which
+ * nothing sets (:351,364 / :331,345), so there is no reference output.  Restated from the
+ * source text as the float32 evaluation JAX performs with weak Python scalars and x64 off:
+ * Python-only sub-expressions are folded in double first, everything touching an array value
+ * is float32, left to right.  episode_step := 0 at reset.  step() is overridden wholesale:
+ * no action clip, no base constraint loop, no -1000 shutdown.
+ * ---------------------------------------------------------------------------- */
+typedef struct {
+    float reward; int terminated, truncated, viol_mask, shutdown;
+} adv_out_t;
+
+static void acr_reset(float *s)                                       /* advanced_chemical_reactor.py:158-193 */
+{
+    static const float init[20] = {323.15f, 313.15f, 2e5f, 2.0f, 1.5f, 0.1f, 0.1f, 0.001f, 0.001f, 0.005f, 300.0f, 0.8f,
+                                   323.15f, 323.15f, 323.15f, 323.15f, 1000.0f, 0.05f, 50.0f, 60.0f};
+    memcpy(s, init, sizeof init);
+}
+
+static void acr_step(const float *s, const float *a, int step_pre, int max_steps, float dt, int flavor, float *o, adv_out_t *out)
+{
+    float T = s[0], Tj = s[1], cA = s[3], cB = s[4], cC = s[5], cD = s[6], Ff = s[7], Fp = s[8], Fc = s[9], hc = s[10], mix = s[11];
+    int estop = a[5] > 0.5f;                                           /* :219-223 */
+    float feed_a = estop ? 0.0f : a[0], cool_a = estop ? 0.01f : a[1], rpm = estop ? 0.0f : a[2];
+    float nFf = Ff + 0.1f * (feed_a - Ff);                             /* :226 */
+    float nFc = Fc + 0.2f * (cool_a - Fc);                             /* :227 */
+    float k = 1e8f * o_expf(-83140.0f / (8.314f * T), flavor);         /* :230 */
+    float rr = ((k * cA) * cB) * mix;                                  /* :231 */
+    float dA = ((nFf * 5.0f - Fp * cA) / 1.0f) - rr;                   /* :234-237 */
+    float dB = ((nFf * 3.0f - Fp * cB) / 1.0f) - rr;
+    float dC = (((-Fp) * cC) / 1.0f) + rr;
+    float dD = (((-Fp) * cD) / 1.0f) + rr;
+    float Qgen = (50000.0f * rr) * 1.0f;                               /* :240 */
+    float Qj = (hc * 4.835975862049409f) * (T - Tj);                   /* :243, jacket_area :78 */
+    float Qw = 0.0f;
+    for (int i = 0; i < 4; i++) Qw = Qw + 6044.969827561761f * (T - s[12 + i]);   /* :246-250 */
+    float Qf = ((nFf * 1000.0f) * 4180.0f) * (a[3] - T);               /* :253 */
+    float dTr = (((Qgen - Qj) - Qw) + Qf) / 4180000.0f;                /* :256-259 */
+    float dTj = (Qj - ((nFc * 1000.0f) * 4180.0f) * (Tj - 293.15f)) / 418000.0f;  /* :262-266 */
+    float nTw[4];
+    for (int i = 0; i < 4; i++) {                                      /* :269-280 */
+        float w = s[12 + i];
+        float wd = (5000.0f * (T - w) - 10.0f * (w - 293.15f)) / 25000.0f;
+        nTw[i] = w + dt * wd;
+    }
+    float moles = (((cA + cB) + cC) + cD) * 1.0f;                      /* :284 */
+    float vp = 1000.0f * o_expf(20.0f - 5000.0f / T, flavor);          /* :287 */
+    float nP = ((((8.314f * T) * moles) / 1.0f) + vp) + 1e5f;          /* :290-292 */
+    if (nP > 2400000.0f) nP = nP - (a[4] / 100.0f) * (nP - 2400000.0f);/* :295-297 */
+    float nmix = o_tanhf(rpm / 1000.0f, flavor) * 0.9f + 0.1f;         /* :300 */
+    float Re = ((rpm * 0.1f) * 1000.0f) / 0.001f;                      /* :301 */
+    float Nu = 0.023f * o_powf(Re, 0.8f, flavor);                      /* :302 */
+    float nhc = (Nu * 0.6f) / 0.1f;                                    /* :303 */
+    float nFp = 0.001f * (1.0f + 0.5f * ((nP - 1e5f) / 1e5f));         /* :306-307 */
+    float nA = fmaxf(0.0f, cA + dt * dA), nB = fmaxf(0.0f, cB + dt * dB), nC = fmaxf(0.0f, cC + dt * dC), nD = fmaxf(0.0f, cD + dt * dD);
+    float nT = T + dt * dTr, nTj = Tj + dt * dTj;                      /* :315-316 */
+    float tau = 1.0f / fmaxf(nFp, 1e-6f);                              /* :319 */
+    float conv = (2.0f - nA) / 2.0f;                                   /* :322-323 */
+    float mT = ((673.15f - nT) / 673.15f) * 100.0f, mP = ((5e6f - nP) / 5e6f) * 100.0f;   /* :326-327 */
+    float st[20] = {nT, nTj, nP, nA, nB, nC, nD, nFf, nFp, nFc, nhc, nmix, nTw[0], nTw[1], nTw[2], nTw[3], tau, conv, mT, mP};
+    memcpy(o, st, sizeof st);
+    float pr = 100.0f * (nC / 5.0f + conv);                            /* :379 */
+    float sr = (mT + mP) / 2.0f;                                       /* :382 */
+    float te = 1.0f - fabsf(nT - 373.15f) / 100.0f, pe = 1.0f - fabsf(nP - 3e5f) / 1e5f;  /* :385-386 */
+    float er = 50.0f * (te + pe);                                      /* :388 */
+    float cp = (-((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4]))) * 10.0f;   /* :391 */
+    float ep = estop ? -1000.0f : 0.0f;                                /* :394 */
+    out->reward = (((pr + sr) + er) + cp) + ep;                        /* :396-402 */
+    out->viol_mask = ((nT > 673.15f) ? 1 : 0) | ((nP > 5e6f) ? 2 : 0) | ((mT < 10.0f) ? 4 : 0) | ((mP < 10.0f) ? 8 : 0);  /* :433-443 */
+    out->terminated = (nT > 673.15f) || (nP > 5e6f) || (nC > 8.0f);    /* :412-420 */
+    out->truncated = step_pre >= max_steps;                            /* :351 */
+    out->shutdown = estop;                                             /* :359 */
+}
+
+static void apg_reset(float *s)                                        /* advanced_power_grid.py:182-226 */
+{
+    static const float init[32] = {1, 1, 1, 1, 1, 1, 1, 1, 0.0f, -0.1f, 0.05f, -0.05f, 0.02f, -0.02f, 0.08f, -0.08f,
+                                   50, 50, 50, 50, 30, 25, 20, 28, 25, 20, 30, 18, 15, -12, 18, -14};
+    memcpy(s, init, sizeof init);
+}
+
+static void apg_step(const float *s, const float *a, int step_pre, int max_steps, float dt, int flavor, float *o, adv_out_t *out)
+{
+    static const float H[4] = {5.0f, 4.0f, 3.5f, 4.5f}, D[4] = {1.0f, 0.8f, 0.9f, 1.1f};          /* :79-85 */
+    static const float Pmax[4] = {50.0f, 40.0f, 35.0f, 45.0f}, Pmin[4] = {10.0f, 8.0f, 7.0f, 9.0f}, ramp[4] = {2.0f, 1.8f, 1.5f, 2.2f};
+    static const float bl0[4] = {25.0f, 20.0f, 30.0f, 18.0f}, al[4] = {1.5f, 1.2f, 1.8f, 1.3f}, Kf[4] = {1.0f, 0.8f, 1.2f, 0.9f};  /* :93-97 */
+    int emerg = a[7] > 0.5f;                                           /* :246-249 */
+    float shed = emerg ? fminf(a[6] + 10.0f, 30.0f) : a[6];
+    float sp[4], nf[4], nPg[4], nL[4], fsum = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        sp[i] = emerg ? a[i] * 0.7f : a[i];
+        float pm = sp[i] / 100.0f, pe = s[20 + i] / 100.0f;            /* :261-262 */
+        float df = ((pm - pe) - D[i] * (s[16 + i] - 50.0f)) / (2.0f * H[i]);   /* :264-265 */
+        nf[i] = s[16 + i] + dt * df;                                   /* :272 */
+        fsum = fsum + nf[i] * H[i];                                    /* :276 */
+    }
+    float fsys = fsum / 17.0f;
+    for (int i = 0; i < 4; i++) {                                      /* :279-289 */
+        float mr = ramp[i] * dt, ch = sp[i] - s[20 + i];
+        ch = fminf(fmaxf(ch, -mr), mr);
+        nPg[i] = fminf(fmaxf(s[20 + i] + ch, Pmin[i]), Pmax[i]);
+    }
+    float fdev = (fsys - 50.0f) / 50.0f;                               /* :304 */
+    for (int i = 0; i < 4; i++) {                                      /* :293-308 */
+        float bl = bl0[i];
+        if (i == 0) bl = fmaxf(bl - shed, 0.0f);
+        float ve = o_powf(s[i] / 1.0f, al[i], flavor);
+        float fe = 1.0f + Kf[i] * fdev;
+        nL[i] = (bl * ve) * fe;
+    }
+    float nV[8], nTh[8];
+    for (int i = 0; i < 8; i++) {                                      /* :368-389 */
+        float inj = (i < 4) ? nPg[i] / 100.0f : (-nL[i - 4]) / 100.0f;
+        float v = s[i] + 0.01f * inj;
+        if (i == 0) v = a[4];
+        if (i == 1) v = a[5];
+        nV[i] = fminf(fmaxf(v, 0.8f), 1.2f);
+        nTh[i] = s[8 + i] + 0.05f * inj;
+    }
+    float flow[4];
+    for (int i = 0; i < 4; i++) flow[i] = (((nV[i] * nV[i + 4]) / 0.1f) * o_sinf(nTh[i] - nTh[i + 4], flavor)) * 100.0f;   /* :395-405 */
+    float vmax = 0.0f, vmean = 0.0f, thmax = nTh[0], thmin = nTh[0], fmaxd = 0.0f;
+    int vviol = 0;
+    for (int i = 0; i < 8; i++) {
+        float dv = fabsf(nV[i] - 1.0f);
+        vmax = fmaxf(vmax, dv); vmean = vmean + dv;
+        if (dv > 0.05f) vviol = 1;
+        thmax = fmaxf(thmax, nTh[i]); thmin = fminf(thmin, nTh[i]);
+    }
+    vmean = vmean / 8.0f;
+    for (int i = 0; i < 4; i++) fmaxd = fmaxf(fmaxd, fabsf(nf[i] - 50.0f));
+    float stab = fmaxf(fminf(fminf(1.0f - vmax, 1.0f - (thmax - thmin) / 3.14159265358979323846f), 1.0f - fmaxd / 0.5f), 0.0f);   /* :417-434 */
+    for (int i = 0; i < 8; i++) { o[i] = nV[i]; o[8 + i] = nTh[i]; }
+    for (int i = 0; i < 4; i++) { o[16 + i] = nf[i]; o[20 + i] = nPg[i]; o[24 + i] = nL[i]; o[28 + i] = flow[i]; }
+    float ferr = fabsf(fsys - 50.0f);                                  /* :446-480 */
+    float r_f = 100.0f * o_expf((-ferr) / 0.1f, flavor);
+    float r_v = 50.0f * o_expf((-vmean) / 0.05f, flavor);
+    float tg = ((nPg[0] + nPg[1]) + nPg[2]) + nPg[3], tl = ((nL[0] + nL[1]) + nL[2]) + nL[3];
+    float r_b = 30.0f * o_expf((-fabsf(tg - tl)) / 10.0f, flavor);
+    float r_e = -(0.01f * ((((nPg[0] * nPg[0]) + (nPg[1] * nPg[1])) + (nPg[2] * nPg[2])) + (nPg[3] * nPg[3])));
+    float r_c = (-(((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4])) + fabsf(a[5]))) * 1.0f;
+    out->reward = (((((r_f + r_v) + r_b) + r_e) + r_c) + (-a[6]) * 50.0f) + (-a[7]) * 200.0f;
+    int glim = 0;
+    for (int i = 0; i < 4; i++) if (nPg[i] < Pmin[i] || nPg[i] > Pmax[i]) glim = 1;   /* :521-523 */
+    out->viol_mask = ((ferr > 0.5f) ? 1 : 0) | (vviol ? 2 : 0) | (glim ? 4 : 0);
+    out->terminated = (ferr > 0.5f) || vviol || (stab < 0.1f);         /* :492-501 */
+    out->truncated = step_pre >= max_steps;                            /* :331 */
+    out->shutdown = emerg;
+}
+
+static const float ACT_LOW[5][8] = {{-1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1},
+                                    {0, 0, 0, 273.15f, 0, 0}, {10, 8, 7, 9, 0.95f, 0.95f, 0, 0}};
+static const float ACT_HIGH[5][8] = {{1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1},
+                                     {0.01f, 0.01f, 3000, 473.15f, 100, 1}, {50, 40, 35, 45, 1.05f, 1.05f, 20, 1}};
+
 /* ------------------------------------------------------------------------------
  * IndustrialEnv.reset / IndustrialEnv.step   (base.py:133-213)
  * ---------------------------------------------------------------------------- */
@@ -479,7 +676,9 @@ void oracle_reset(int env, const double *noise, int flavor, float *state)
 {
     if (env == ORACLE_CR) cr_reset(noise, state);
     else if (env == ORACLE_PG) pg_reset(noise, state);
-    else ra_reset(noise, flavor, state);
+    else if (env == ORACLE_RA) ra_reset(noise, flavor, state);
+    else if (env == ORACLE_ACR) acr_reset(state);
+    else apg_reset(state);
 }
 
 typedef struct {
@@ -487,6 +686,8 @@ typedef struct {
     int terminated, truncated;
     int violation_count, critical_violations;   /* SafetyMetrics of this step (base.py:94-124) */
     int ok[3];            /* per-constraint: 1 satisfied */
+    int viol_mask;        /* bit k: condition k violated (the Advanced envs have up to 4) */
+    int shutdown;         /* info['critical_shutdown'] / info['emergency_shutdown'|'emergency_active'] */
 } oracle_step_out_t;
 
 /* One IndustrialEnv.step on one env instance.  step_pre = current_step before the call. */
@@ -495,6 +696,16 @@ void oracle_step(int env, const float *state, const float *action_raw, const dou
                  float *next, oracle_step_out_t *out)
 {
     const oracle_spec_t *sp = &SPECS[env];
+    if (env == ORACLE_ACR || env == ORACLE_APG) {              /* step() overridden wholesale */
+        adv_out_t ao;
+        if (env == ORACLE_ACR) acr_step(state, action_raw, step_pre, max_steps, (float)dt, flavor, next, &ao);
+        else apg_step(state, action_raw, step_pre, max_steps, (float)dt, flavor, next, &ao);
+        out->reward = (double)ao.reward; out->terminated = ao.terminated; out->truncated = ao.truncated;
+        out->viol_mask = ao.viol_mask; out->violation_count = __builtin_popcount(ao.viol_mask);
+        out->critical_violations = 0; out->shutdown = ao.shutdown;
+        for (int k = 0; k < 3; k++) out->ok[k] = !((ao.viol_mask >> k) & 1);
+        return;
+    }
     float a[8];
     for (int i = 0; i < sp->action_dim; i++) {                 /* base.py:167 np.clip(action, -1, 1) */
         float x = action_raw[i];
@@ -532,12 +743,14 @@ void oracle_step(int env, const float *state, const float *action_raw, const dou
     out->terminated = term; out->truncated = trunc;
     out->violation_count = viol; out->critical_violations = crit;
     for (int k = 0; k < 3; k++) out->ok[k] = ok[k];
+    out->viol_mask = (!ok[0] ? 1 : 0) | (!ok[1] ? 2 : 0) | (!ok[2] ? 4 : 0);
+    out->shutdown = crit > 0;
 }
 
 /* batched convenience for tests: row-major [n][S] states etc. */
 void oracle_step_batch(int env, int n, const float *states, const float *actions, const double *noise,
                        const int *step_pre, int max_steps, double dt, int flavor,
-                       float *next, double *reward, int *term, int *trunc, int *viol, int *crit, int *ok)
+                       float *next, double *reward, int *term, int *trunc, int *viol, int *crit, int *ok, int *mask)
 {
     const oracle_spec_t *sp = &SPECS[env];
     for (int i = 0; i < n; i++) {
@@ -548,6 +761,7 @@ void oracle_step_batch(int env, int n, const float *states, const float *actions
         reward[i] = o.reward; term[i] = o.terminated; trunc[i] = o.truncated;
         viol[i] = o.violation_count; crit[i] = o.critical_violations;
         for (int k = 0; k < 3; k++) ok[i * 3 + k] = o.ok[k];
+        if (mask) mask[i] = o.viol_mask | (o.shutdown << 8);
     }
 }
 
@@ -656,7 +870,8 @@ void oracle_gen_actions(int env, uint64_t seed, uint64_t env_index, uint32_t t, 
 {
     double u[8];
     gen_uniforms(seed, env_index, t, STREAM_ACTION, SPECS[env].action_dim, u);
-    for (int i = 0; i < SPECS[env].action_dim; i++) a[i] = (float)(2.0 * u[i] - 1.0);
+    for (int i = 0; i < SPECS[env].action_dim; i++)
+        a[i] = (float)((double)ACT_LOW[env][i] + ((double)ACT_HIGH[env][i] - (double)ACT_LOW[env][i]) * u[i]);
 }
 
 /* ------------------------------------------------------------------------------

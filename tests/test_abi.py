@@ -39,7 +39,11 @@ def test_static_queries_match_reference_constants(oracle):
         osp = oracle.spec(name)
         assert list(sp.penalty) == list(osp.penalty) and list(sp.critical) == list(osp.critical)
         assert sp.dt == osp.dt == 0.1 and sp.n_constraints == 3
-    assert L.nig_env_id(b"AdvancedChemicalReactor-v0") == -1
+    assert L.nig_env_id(b"AdvancedChemicalReactor-v0") == 3 and L.nig_env_id(b"AdvancedPowerGrid-v0") == 4
+    for eid, key, S, A, T in ((3, "acr", 20, 6, 1000), (4, "apg", 32, 8, 500)):
+        sp, osp = ni._lib.env_spec(eid), oracle.spec(key)
+        assert (sp.state_dim, sp.action_dim, sp.max_episode_steps, sp.k_step, sp.k_reset) == (S, A, T, 0, 0)
+        assert (osp.state_dim, osp.action_dim, osp.max_episode_steps) == (S, A, T) and sp.n_constraints == osp.n_constraints
     assert L.nig_env_id(b"nope") == -1
 
 
@@ -72,7 +76,8 @@ def test_no_cpu_fallback():
         ni.make("ChemicalReactor-v0")
     with pytest.raises(RuntimeError):
         ni.make_batched("PowerGrid-v0", 8)
-    with pytest.raises(ValueError, match="Unknown environment 'Foo-v0'. Available: ChemicalReactor-v0"):
+    with pytest.raises(ValueError, match="Unknown environment 'Foo-v0'. Available: ChemicalReactor-v0, PowerGrid-v0, RobotAssembly-v0, "
+                                         "AdvancedChemicalReactor-v0, AdvancedPowerGrid-v0"):
         ni.make("Foo-v0")
 
 
