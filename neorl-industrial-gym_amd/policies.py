@@ -153,3 +153,38 @@ def behaviour_policy(env_id: str, quality: str) -> DevicePolicy:
         return DevicePolicy(S, A, W=W, b=b, half_range=[0, 0, 0, 0.5, 0.5, 0.5, 0.5], p_uniform=0.3,
                             uniform_range=0.8, clip=(-2.0, 2.0))
     raise ValueError(env_id)
+
+
+class MLPPolicy:
+    """The deterministic actor of the reference's agents -- (S -> 256 -> 256 -> A) ReLU MLP with a
+    tanh head (agents/networks.py:47-70,125-144; cql.py:339-343) -- kept on the GPU.
+
+    `weights` = [(W1 [S,H], b1 [H]), (W2 [H,H], b2 [H]), (W3 [H,A], b3 [A])] as exported from the
+    agent (Flax Dense kernels are [in, out]).  evaluate_with_safety() calls `predict_device`, so
+    observations and actions never leave the device; `predict` is the host form of the same net
+    (agent.predict contract, agents/base.py:106-141)."""
+    is_trained = True
+
+    def __init__(self, weights, device="cuda:0"):
+        import torch
+        self.device = torch.device(device)
+        self.layers = [(torch.as_tensor(np.asarray(W), dtype=torch.float32, device=self.device).contiguous(),
+                        torch.as_tensor(np.asarray(b), dtype=torch.float32, device=self.device).contiguous())
+                       for W, b in weights]
+        self.state_dim = self.layers[0][0].shape[0]
+        self.action_dim = self.layers[-1][0].shape[1]
+
+    def predict_device(self, obs):
+        import torch
+        x = obs
+        for i, (W, b) in enumerate(self.layers):
+            x = torch.addmm(b, x, W)
+            x = torch.relu(x) if i + 1 < len(self.layers) else torch.tanh(x)
+        return x
+
+    def predict(self, observations, deterministic: bool = True):
+        import torch
+        o = torch.as_tensor(np.asarray(observations, dtype=f32), device=self.device)
+        single = o.dim() == 1
+        out = self.predict_device(o.reshape(-1, self.state_dim)).cpu().numpy()
+        return out[0] if single else out

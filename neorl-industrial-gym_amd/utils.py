@@ -45,6 +45,14 @@ def _predict(agent, obs_dev: torch.Tensor) -> torch.Tensor:
     return torch.as_tensor(np.asarray(act, dtype=np.float32))
 
 
+def _round_is_over(env, t: int, on_device: bool) -> bool:
+    """All lanes finished?  Reading the answer synchronises the stream, so a device-resident
+    policy is only asked every 16 steps (finished lanes are frozen; extra steps are no-ops)."""
+    if on_device and (t % 16) != 0 and t <= env.max_episode_steps:
+        return False
+    return bool(env.done.all().item())
+
+
 def evaluate_with_safety(agent: Any, env: Any, n_episodes: int = 100, record_video: bool = False,
                          render: bool = False, step_noise_fn=None, reset_noise_fn=None) -> Dict[str, Any]:
     """utils.py:42-154.  With a single env this is the reference's loop verbatim in behaviour;
@@ -134,7 +142,7 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
             act = _predict(agent, env.obs)
             env.step(act, step_noise=None if step_noise_fn is None else step_noise_fn(rnd, t), layout="aos")
             t += 1
-            if bool(env.done.all().item()) or t > _lib.MAX_EPISODE_STEPS:
+            if _round_is_over(env, t, hasattr(agent, "predict_device")) or t > _lib.MAX_EPISODE_STEPS:
                 break
         remaining -= k
         rnd += 1
