@@ -286,6 +286,24 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
                        int64_t out_stride, float *obs_out, int64_t obs_step_stride,
                        float *act_out, int64_t ld_act, int64_t act_step_stride, void *stream);
 
+/*
+ * Closed-loop rollouts with the reference agents' deterministic ACTOR on the device: a
+ * (S -> 256 -> 256 -> A) ReLU MLP with a tanh head (agents/networks.py:47-70,125-144;
+ * cql.py:339-343) evaluated with float32-input MFMA (v_mfma_f32_32x32x2_f32: an exact k-ordered
+ * float32 fma chain) and fused with IndustrialEnv.step in one kernel: 32 envs per wavefront, the
+ * hidden activations never leave the accumulator registers (an accumulator tile is the next
+ * layer's B operand as it stands).  Weights are host pointers, row-major [in][out] (the layout of
+ * a Flax Dense kernel); the library re-orders them once into the MFMA operand stream and keeps
+ * that copy in device memory it owns.  hidden must be 256.
+ */
+int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const float *b1, const float *W2,
+                       const float *b2, const float *W3, const float *b3, void *stream);
+
+/* As nig_rollout_policy, with the MLP actor installed by nig_set_mlp_policy. */
+int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out,
+                    int64_t out_stride, float *obs_out, int64_t obs_step_stride,
+                    float *act_out, int64_t ld_act, int64_t act_step_stride, void *stream);
+
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);

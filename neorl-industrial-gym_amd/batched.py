@@ -336,9 +336,23 @@ class BatchedIndustrialEnv:
             _lib.check(self._L.nig_set_policy(self._h, C.byref(P), self._stream()))
         self._policy = policy
 
+    def set_mlp_policy(self, weights):
+        """Install the reference agents' actor (S->256->256->A, ReLU, tanh) for rollout_mlp():
+        weights = [(W1 [S,256], b1), (W2 [256,256], b2), (W3 [256,A], b3)], host arrays, [in, out]."""
+        W = [np.ascontiguousarray(np.asarray(x), dtype=np.float32) for pair in weights for x in pair]
+        S, A, Hd = self.state_dim, self.action_dim, 256
+        assert [w.shape for w in W] == [(S, Hd), (Hd,), (Hd, Hd), (Hd,), (Hd, A), (A,)], [w.shape for w in W]
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_set_mlp_policy(self._h, Hd, *[w.ctypes.data_as(C.c_void_p) for w in W], self._stream()))
+
+    def rollout_mlp(self, n_steps: int, reward_out=None, flags_out=None, obs_out=None, act_out=None):
+        """Closed loop with the installed MLP actor evaluated by f32 MFMA inside the env kernel
+        (same outputs as rollout_policy)."""
+        self.rollout_policy(n_steps, reward_out, flags_out, obs_out, act_out, _fn=self._L.nig_rollout_mlp)
+
     def rollout_policy(self, n_steps: int, reward_out: Optional[torch.Tensor] = None,
                        flags_out: Optional[torch.Tensor] = None, obs_out: Optional[torch.Tensor] = None,
-                       act_out: Optional[torch.Tensor] = None):
+                       act_out: Optional[torch.Tensor] = None, _fn=None):
         """n_steps closed-loop steps (action = installed policy(observation)) in ONE launch.
         obs_out: float32 contiguous [n_steps, B, S] (observation the policy acted on);
         act_out: float32 [n_steps, A, >=B]; reward_out / flags_out: [n_steps, >=B] or [B]."""
@@ -365,8 +379,8 @@ class BatchedIndustrialEnv:
             assert act_out.shape[0] >= n_steps and act_out.shape[1] == self.action_dim and act_out.shape[2] >= self.batch
             ap, lda, sa = C.c_void_p(act_out.data_ptr()), act_out.stride(1), act_out.stride(0)
         with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.nig_rollout_policy(self._h, int(n_steps), rp, fp, rs or fs, op, so, ap, lda, sa,
-                                                  self._stream()))
+            _lib.check((_fn or self._L.nig_rollout_policy)(self._h, int(n_steps), rp, fp, rs or fs, op, so, ap, lda, sa,
+                                                           self._stream()))
 
     def get_dataset(self, quality: str = "mixed", scale: int = 1, chunk: int = 100):
         """Batched env.get_dataset(quality): every lane is one episode of the reference's

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -674,6 +675,178 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused MLP actor + env step (the one contraction on this path, so the one place for MFMA).
+//
+// One wavefront = 32 env instances.  Everything is computed TRANSPOSED, h^T = W^T x^T, so that
+//   * the A operand is the weight matrix (one float per lane, streamed from a pre-ordered
+//     array: record r = 64 floats = one 256-byte coalesced load),
+//   * the B operand has the env on the lane (l & 31) and the k index on the lane half (l >> 5),
+//   * the 32x32 result tile has the env on the lane again and the hidden unit in the register,
+// which makes an accumulator register of layer n directly usable as a B operand of layer n+1
+// (register t of a tile holds hidden rows rho_h(t) = (t&3) + 8(t>>2) + 4h of that tile for lane
+// half h; the weight stream is ordered to match).  No LDS, no transposes, no conversion.
+// v_mfma_f32_32x32x2_f32 is bit-for-bit fma(a1,b1, fma(a0,b0, c)) (k0 = lane half 0, then k1), so
+// the CPU oracle reproduces the actor exactly.  Biases ride along as one extra k-step per tile
+// (A = bias on half 0 / 0 on half 1, B = 1 / 0).
+// Both lane halves carry the full env state and run the env step redundantly (it is ~3 % of the
+// MFMA time); lanes 32-63 never store.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct MlpArgs {
+    StepArgs s;
+    const float *wstream;       // MFMA operand stream built by nig_set_mlp_policy
+    int n_steps;
+    uint32_t out_stride;
+    float *obs_out; uint64_t obs_step_stride;
+    float *act_out; uint32_t ld_act_out; uint64_t act_step_stride;
+};
+
+constexpr int MLP_H = 256, MLP_MT = MLP_H / 32;
+__host__ __device__ constexpr int mlp_records(int S) { return MLP_MT * (S / 2 + 1) + MLP_MT * (MLP_MT * 16 + 1 + 16) + 1; }
+
+template <class Env>
+__global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
+{
+    constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
+    constexpr int KSN = KS > 0 ? KS : 1;
+    static_assert(S % 2 == 0 && A <= 8, "MFMA actor needs an even state dim and at most 8 actions");
+    const StepArgs &p = q.s;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
+    const uint32_t lane0 = blockIdx.x * (BLOCK / 2) + (tid >> 6) * 32u;     // first env of this wave
+    const uint32_t li = lane0 + e;
+    const bool in_range = li < p.B;
+    const bool writer = in_range && half == 0;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
+    const uint64_t gi = p.env0 + (uint64_t)li;
+    const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
+    const bool tally = p.tally != nullptr;
+
+    uint32_t ctr = in_range ? p.ctr[li] : (uint32_t)NIG_CTR_DONE;
+    float s[S], a[A], n[S];
+    double nz[KSN];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + k * p.ld_state)[li] : 0.0f;
+    double ret = (tally && in_range) ? p.ep_ret[li] : 0.0;
+    LaneTally lt;
+    lt.clear();
+    const float *wl = q.wstream + lane;
+
+    for (int it = 0; it < q.n_steps; ++it) {
+        // ---------------- actor: 3 layers of f32 MFMA, whole wave (EXEC all ones) ----------------
+        const float *w = wl;
+        f32x16 h1[MLP_MT];
+#pragma unroll
+        for (int m = 0; m < MLP_MT; ++m) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < S / 2; ++ks) {
+                const float b = half ? s[2 * ks + 1] : s[2 * ks];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], b, acc, 0, 0, 0);
+                w += 64;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b1
+            w += 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);                               // ReLU
+            h1[m] = acc;
+        }
+        f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int m2 = 0; m2 < MLP_MT; ++m2) {          // a real loop: the body is 145 MFMAs of straight-line code
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < MLP_MT; ++kt) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], h1[kt][t], acc, 0, 0, 0);
+                    w += 64;
+                }
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b2
+            w += 64;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {             // this h2 tile is consumed at once by the head
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], fmaxf(acc[t], 0.0f), out, 0, 0, 0);
+                w += 64;
+            }
+        }
+        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, out, 0, 0, 0);       // + b3
+        // action j sits in register j&3 of lane half j>>2: hand every lane all A of them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mine = out[r];
+            const float other = __shfl_xor(mine, 32);
+            if (r < A) a[r] = det_tanhf(half ? other : mine);
+            if (r + 4 < A) a[r + 4] = det_tanhf(half ? mine : other);
+        }
+
+        // ---------------- IndustrialEnv.step (both lane halves, identical results) ----------------
+        const uint32_t orow = (uint32_t)it * q.out_stride;
+        const bool frozen = (ctr & NIG_CTR_DONE) != 0;
+        if (writer && !frozen) {
+            if (q.obs_out) {
+                float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) + (size_t)li * (S / 4);
+#pragma unroll
+                for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+            }
+            if (q.act_out) {
+                float *ao = q.act_out + (size_t)it * q.act_step_stride;
+#pragma unroll
+                for (int j = 0; j < A; ++j) (ao + j * q.ld_act_out)[li] = a[j];
+            }
+        }
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+        StepResult<Env> res;
+        step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
+        const int step = step_pre + 1;
+        const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+        const bool done = (res.terminated || res.truncated) && !frozen;
+        uint32_t fl = pack_flags<Env>(res, step) | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
+        float rew = (float)res.reward;
+        if (frozen) {
+            fl = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+            rew = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) n[k] = s[k];
+        } else {
+            ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+            if (tally) {
+                if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
+                else ret = ret + (double)res.reward;
+            }
+        }
+        if (writer) {
+            if (p.reward) (p.reward + orow)[li] = rew;
+            if (p.flags) (p.flags + orow)[li] = fl;
+        }
+        if (done) {
+            lt.life += (long long)viol_ep;
+            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (autoreset) {
+                double rn[KR > 0 ? KR : 1];
+                Env::draw_init(key, rn);
+                Env::init(rn, n);
+                ctr = 0u;
+            } else {
+                ctr |= NIG_CTR_DONE;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = n[k];
+    }
+    if (!writer) return;
+#pragma unroll
+    for (int k = 0; k < S; ++k) (p.state + k * p.ld_state)[li] = s[k];
+    p.ctr[li] = ctr;
+    if (lt.life != 0) p.life_viol[li] += lt.life;
+    if (tally) {
+        p.ep_ret[li] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + li, p.ld);
+    }
+}
+
 struct ResetArgs {
     float *state; uint32_t *ctr; long long *life_viol; double *ep_ret;
     int64_t ld; int64_t B; int64_t ld_state;
@@ -825,6 +998,7 @@ struct nig_handle {
     nig_policy *pol_dev;   // device copy of the installed policy
     nig_policy pol_host;   // staging copy (must outlive the async H2D copy)
     bool has_policy;
+    float *mlp_stream;     // device copy of the MFMA operand stream of the MLP actor (owned)
 };
 
 struct nig_plan {
@@ -1012,7 +1186,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
     h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false;
+    h->has_policy = false; h->mlp_stream = nullptr;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -1034,6 +1208,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
 int nig_destroy(nig_handle *h)
 {
     if (!h) return NIG_OK;
+    if (h->mlp_stream) (void)hipFree(h->mlp_stream);
     if (h->owns_ws && h->ws) (void)hipFree(h->ws);
     delete h;
     return NIG_OK;
@@ -1204,6 +1379,81 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
     q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
     hipStream_t st = (hipStream_t)stream;
     NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_policy_kernel<E>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q));
+    HIP_TRY(hipGetLastError());
+    h->t += (uint32_t)n_steps;
+    return NIG_OK;
+}
+
+// Row of a 32x32 MFMA result tile held in register t by lane half hf (MI355X_MICROARCH / guide section 3).
+static inline int mfma_row(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
+
+int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const float *b1, const float *W2, const float *b2,
+                       const float *W3, const float *b3, void *stream)
+{
+    if (!h || !W1 || !b1 || !W2 || !b2 || !W3 || !b3) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: NULL argument%s");
+    if (hidden != MLP_H) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: hidden must be 256 (agents/networks.py default)%s");
+    const int S = SPECS[h->env].state_dim, A = SPECS[h->env].action_dim, H = MLP_H;
+    if (S % 2 != 0 || A > 8) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: env shape not supported%s");
+    const int nrec = mlp_records(S);
+    float *host = (float *)calloc((size_t)nrec * 64, sizeof(float));
+    if (!host) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: out of host memory%s");
+    // Build the operand stream in exactly the order rollout_mlp_kernel consumes it.  Record = 64 floats;
+    // lane l = (i = l & 31, hf = l >> 5) holds W[k(hf)][32*tile + i].
+    int r = 0;
+    for (int m = 0; m < MLP_MT; ++m) {                      // layer 1, natural k order: k = 2*ks + hf
+        for (int ks = 0; ks < S / 2; ++ks, ++r)
+            for (int l = 0; l < 64; ++l) host[(size_t)r * 64 + l] = W1[(size_t)(2 * ks + (l >> 5)) * H + 32 * m + (l & 31)];
+        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b1[32 * m + l];
+        ++r;
+    }
+    for (int m2 = 0; m2 < MLP_MT; ++m2) {
+        for (int kt = 0; kt < MLP_MT; ++kt)                   // layer 2: k follows the accumulator register order of h1
+            for (int t = 0; t < 16; ++t, ++r)
+                for (int l = 0; l < 64; ++l)
+                    host[(size_t)r * 64 + l] = W2[(size_t)(32 * kt + mfma_row(t, l >> 5)) * H + 32 * m2 + (l & 31)];
+        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b2[32 * m2 + l];
+        ++r;
+        for (int t = 0; t < 16; ++t, ++r)                     // head: rows i >= A are zero
+            for (int l = 0; l < 64; ++l)
+                if ((l & 31) < A) host[(size_t)r * 64 + l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+    }
+    for (int l = 0; l < A; ++l) host[(size_t)r * 64 + l] = b3[l];
+    ++r;
+    if (r != nrec) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
+    hipError_t e = hipSuccess;
+    if (!h->mlp_stream) e = hipMalloc((void **)&h->mlp_stream, (size_t)mlp_records(32) * 64 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)nrec * 64 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    if (e != hipSuccess) return fail(NIG_ERR_HIP, "nig_set_mlp_policy: %s", hipGetErrorString(e));
+    return NIG_OK;
+}
+
+int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                    float *obs_out, int64_t obs_step_stride, float *act_out, int64_t ld_act, int64_t act_step_stride,
+                    void *stream)
+{
+    if (!h || n_steps <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: bad argument%s");
+    if (!h->mlp_stream) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: no actor installed (nig_set_mlp_policy)%s");
+    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
+        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: out_stride outside {0} U [batch, 2^26]%s");
+    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: n_steps*out_stride >= 2^32%s");
+    if (obs_out && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
+        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: obs_out needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
+    if (act_out && (ld_act < h->B || ld_act > NIG_MAX_PITCH || act_step_stride < (int64_t)SPECS[h->env].action_dim * ld_act))
+        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: bad action trajectory pitch%s");
+    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: launch counter would wrap%s");
+    MlpArgs q;
+    memset(&q, 0, sizeof q);
+    q.s = base_step_args(h);
+    q.s.reward = reward_out; q.s.flags = flags_out;
+    q.s.t_ptr = nullptr; q.s.t_off = h->t;
+    q.wstream = h->mlp_stream; q.n_steps = n_steps; q.out_stride = (uint32_t)out_stride;
+    q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
+    q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((h->B + BLOCK / 2 - 1) / (BLOCK / 2));     // 32 envs per wave, 128 per block
+    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_mlp_kernel<E>), dim3(grid), dim3(BLOCK), 0, st, q));
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;

@@ -173,6 +173,10 @@ class MLPPolicy:
                        for W, b in weights]
         self.state_dim = self.layers[0][0].shape[0]
         self.action_dim = self.layers[-1][0].shape[1]
+        self.weights = [(np.asarray(W, dtype=f32), np.asarray(b, dtype=f32)) for W, b in weights]
+        # the fused MFMA kernel covers the reference actor shape; anything else goes through torch GEMMs
+        self.fusable = (len(self.weights) == 3 and self.weights[0][0].shape[1] == 256
+                        and self.weights[1][0].shape == (256, 256))
 
     def predict_device(self, obs):
         import torch

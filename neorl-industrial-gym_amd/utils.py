@@ -121,8 +121,12 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
     B = env.batch
     remaining, rnd = int(n_episodes), 0
     device_policy = hasattr(agent, "to_struct") and step_noise_fn is None and reset_noise_fn is None
+    fused_mlp = getattr(agent, "fusable", False) and step_noise_fn is None and reset_noise_fn is None
     if device_policy:
         env.set_policy(agent)
+    elif fused_mlp:
+        env.set_mlp_policy(agent.weights)
+        device_policy = True
     while remaining > 0 and device_policy:
         # the agent runs ON the device: one fused launch plays every episode of the round to its end
         k = min(B, remaining)
@@ -130,7 +134,7 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
         mask[:k] = 1
         env.ctr.fill_(_lib.CTR_DONE)
         env.reset(mask=mask)
-        env.rollout_policy(env.max_episode_steps)
+        (env.rollout_mlp if fused_mlp else env.rollout_policy)(env.max_episode_steps)
         remaining -= k
     while remaining > 0:
         k = min(B, remaining)

@@ -1087,6 +1087,105 @@ void oracle_rollout_policy(int env, int64_t n, uint64_t env0, uint64_t seed, uin
     }
 }
 
+
+/* ------------------------------------------------------------------------------
+ * MLP actor (S -> 256 -> 256 -> A, ReLU, tanh; agents/networks.py:47-70,125-144) in the exact
+ * float32 fma-chain order of the device's MFMA evaluation (v_mfma_f32_32x32x2_f32 is
+ * fma(a1,b1, fma(a0,b0, c)) per k-step): layer 1 in natural k order, layers 2/3 in the order an
+ * accumulator tile exposes its rows (register t of a 32-row tile: rows rho(t), rho(t)+4 with
+ * rho(t) = (t&3) + 8(t>>2)), the bias as a last k-step (fma(b,1,acc), then fma(0,0,acc)).
+ * W are row-major [in][out] (Flax Dense kernel layout).
+ * ---------------------------------------------------------------------------- */
+#define MLP_H 256
+static int mlp_rho(int t) { return (t & 3) + 8 * (t >> 2); }
+
+static void mlp_actor(int S, int A, const float *W1, const float *b1, const float *W2, const float *b2,
+                      const float *W3, const float *b3, const float *obs, int flavor, float *act)
+{
+    float h1[MLP_H], h2[MLP_H];
+    (void)flavor;
+    for (int u = 0; u < MLP_H; u++) {
+        float acc = 0.0f;
+        for (int ks = 0; ks < S / 2; ks++) {
+            acc = fmaf(W1[(size_t)(2 * ks) * MLP_H + u], obs[2 * ks], acc);
+            acc = fmaf(W1[(size_t)(2 * ks + 1) * MLP_H + u], obs[2 * ks + 1], acc);
+        }
+        acc = fmaf(b1[u], 1.0f, acc); acc = fmaf(0.0f, 0.0f, acc);
+        h1[u] = fmaxf(acc, 0.0f);
+    }
+    for (int v = 0; v < MLP_H; v++) {
+        float acc = 0.0f;
+        for (int kt = 0; kt < MLP_H / 32; kt++)
+            for (int t = 0; t < 16; t++) {
+                int k0 = 32 * kt + mlp_rho(t), k1 = k0 + 4;
+                acc = fmaf(W2[(size_t)k0 * MLP_H + v], h1[k0], acc);
+                acc = fmaf(W2[(size_t)k1 * MLP_H + v], h1[k1], acc);
+            }
+        acc = fmaf(b2[v], 1.0f, acc); acc = fmaf(0.0f, 0.0f, acc);
+        h2[v] = fmaxf(acc, 0.0f);
+    }
+    for (int j = 0; j < A; j++) {
+        float acc = 0.0f;
+        for (int kt = 0; kt < MLP_H / 32; kt++)
+            for (int t = 0; t < 16; t++) {
+                int k0 = 32 * kt + mlp_rho(t), k1 = k0 + 4;
+                acc = fmaf(W3[(size_t)k0 * A + j], h2[k0], acc);
+                acc = fmaf(W3[(size_t)k1 * A + j], h2[k1], acc);
+            }
+        acc = fmaf(b3[j], 1.0f, acc); acc = fmaf(0.0f, 0.0f, acc);
+        act[j] = det_tanhf(acc);
+    }
+}
+
+void oracle_mlp_actions(int env, int64_t n, const float *W1, const float *b1, const float *W2, const float *b2,
+                        const float *W3, const float *b3, const float *obs, float *act)
+{
+    const int S = SPECS[env].state_dim, A = SPECS[env].action_dim;
+    for (int64_t i = 0; i < n; i++) mlp_actor(S, A, W1, b1, W2, b2, W3, b3, obs + (size_t)i * S, MATH_POLY, act + (size_t)i * A);
+}
+
+/* closed loop with the MLP actor (same conventions as oracle_rollout_policy) */
+void oracle_rollout_mlp(int env, int64_t n, uint64_t env0, uint64_t seed, uint32_t t0, int T, int max_steps, double dt,
+                        int flavor, int autoreset, int nthreads, const float *W1, const float *b1, const float *W2,
+                        const float *b2, const float *W3, const float *b3, float *state_out, int32_t *step_out,
+                        int32_t *done_out, oracle_tally_t *tally, float *act_traj /* [T][n][A] or NULL */)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    const int S = sp->state_dim, A = sp->action_dim;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        float s[32], nx[32], a[8];
+        double nz[32];
+        uint64_t gi = env0 + (uint64_t)i;
+        oracle_tally_t me; memset(&me, 0, sizeof me);
+        oracle_gen_reset_noise(env, seed, gi, t0, nz);
+        oracle_reset(env, nz, flavor, s);
+        int step = 0, done = 0;
+        for (int k = 0; k < T; k++) {
+            uint32_t t = t0 + 1u + (uint32_t)k;
+            if (done) continue;
+            mlp_actor(S, A, W1, b1, W2, b2, W3, b3, s, flavor, a);
+            if (act_traj) memcpy(act_traj + ((size_t)k * n + i) * A, a, A * sizeof(float));
+            oracle_step_out_t o;
+            oracle_gen_step_noise(env, seed, gi, t, nz);
+            oracle_step(env, s, a, nz, step, max_steps, dt, flavor, nx, &o);
+            me.steps++; me.violations += o.violation_count; me.critical += o.critical_violations; me.reward_sum += o.reward;
+            me.terminated += o.terminated; me.truncated += (o.truncated && !o.terminated);
+            if (o.terminated || o.truncated) {
+                me.episodes++;
+                if (autoreset) { oracle_gen_reset_noise(env, seed, gi, t, nz); oracle_reset(env, nz, flavor, s); step = 0; }
+                else { memcpy(s, nx, S * sizeof(float)); step++; done = 1; }
+            } else { memcpy(s, nx, S * sizeof(float)); step++; }
+        }
+        memcpy(state_out + (size_t)i * S, s, S * sizeof(float));
+        step_out[i] = step; done_out[i] = done;
+        if (tally) tally[i] = me;
+    }
+}
+
 void oracle_policy_action(int env, const oracle_policy_t *P, const float *obs, uint64_t seed, uint64_t gi, uint32_t t,
                           float *integ, float *eprev, float *u)
 {

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Closed-loop throughput with a device-resident policy (GPU box): env-steps/s for
+  mlp-torch   the reference actor shape (S->256->256->A) via torch GEMMs + one step kernel per step
+  affine      an on-device affine policy inside the fused rollout kernel
+usage: python profiles/bench_policy.py [--batch 65536] [--steps 200]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import neorl_industrial_gym_amd as ni
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--env", default="ChemicalReactor-v0")
+args = ap.parse_args()
+B, T = args.batch, args.steps
+env = ni.make_batched(args.env, B, autoreset=True, tally=True)
+S, A = env.state_dim, env.action_dim
+rng = np.random.default_rng(0)
+ws = [(rng.normal(0, 0.02 / np.sqrt(S), (S, 256)), np.zeros(256)), (rng.normal(0, 1 / 16, (256, 256)), np.zeros(256)),
+      (rng.normal(0, 1 / 16, (256, A)), np.zeros(A))]
+pol = ni.MLPPolicy(ws)
+out = {}
+env.reset()
+for _ in range(20):
+    env.step(pol.predict_device(env.obs), layout="aos")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(T):
+    env.step(pol.predict_device(env.obs), layout="aos")
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+out["mlp_torch"] = {"env_steps_per_s": B * T / dt, "us_per_step": dt / T * 1e6}
+env.set_policy(ni.behaviour_policy(args.env, "expert"))
+env.rollout_policy(50)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+env.rollout_policy(T)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+out["affine_fused"] = {"env_steps_per_s": B * T / dt, "us_per_step": dt / T * 1e6}
+print(json.dumps(out))
