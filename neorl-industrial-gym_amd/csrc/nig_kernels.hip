@@ -730,47 +730,69 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     double ret = (tally && in_range) ? p.ep_ret[li] : 0.0;
     LaneTally lt;
     lt.clear();
-    const float *wl = q.wstream + lane;
-
     for (int it = 0; it < q.n_steps; ++it) {
         // ---------------- actor: 3 layers of f32 MFMA, whole wave (EXEC all ones) ----------------
-        const float *w = wl;
+        // A operands come from the pre-ordered weight stream (block-uniform base + lane), one
+        // 256-byte record per MFMA.  An MFMA issues every 64 cycles and an L2 hit takes ~500-900, so
+        // records are fetched RING = 29 MFMAs ahead through a register ring (145 records per
+        // hidden-tile iteration = 5 x 29: ring slots are compile-time constants).
+        const float *w = q.wstream;                          // uniform; lane offset added per access
         f32x16 h1[MLP_MT];
+        {
+            constexpr int R1 = S / 2 + 1;                    // records per layer-1 tile
+            float cur[R1], nxt[R1];
 #pragma unroll
-        for (int m = 0; m < MLP_MT; ++m) {
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < R1; ++j) cur[j] = w[j * 64 + lane];
 #pragma unroll
-            for (int ks = 0; ks < S / 2; ++ks) {
-                const float b = half ? s[2 * ks + 1] : s[2 * ks];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], b, acc, 0, 0, 0);
-                w += 64;
+            for (int m = 0; m < MLP_MT; ++m) {
+                if (m + 1 < MLP_MT) {
+#pragma unroll
+                    for (int j = 0; j < R1; ++j) nxt[j] = w[(R1 + j) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < S / 2; ++ks) {
+                    const float b = half ? s[2 * ks + 1] : s[2 * ks];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ks], b, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[R1 - 1], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b1
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);                                   // ReLU
+                h1[m] = acc;
+                w += R1 * 64;
+#pragma unroll
+                for (int j = 0; j < R1; ++j) cur[j] = nxt[j];
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b1
-            w += 64;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);                               // ReLU
-            h1[m] = acc;
         }
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        constexpr int RING = 29, PER = MLP_MT * 16 + 1 + 16;     // 145 records per m2 iteration
+        static_assert(PER % RING == 0, "ring slots must be static across iterations");
+        float ring[RING];
+#pragma unroll
+        for (int j = 0; j < RING; ++j) ring[j] = w[j * 64 + lane];
         for (int m2 = 0; m2 < MLP_MT; ++m2) {          // a real loop: the body is 145 MFMAs of straight-line code
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const float *wn = w + RING * 64;           // record i + RING (the stream is padded past its end)
 #pragma unroll
-            for (int kt = 0; kt < MLP_MT; ++kt) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], h1[kt][t], acc, 0, 0, 0);
-                    w += 64;
+            for (int i = 0; i < PER; ++i) {
+                const float aop = ring[i % RING];
+                ring[i % RING] = wn[i * 64 + lane];
+                // pin the source order: hipcc's scheduler otherwise sinks every prefetch to just before
+                // its use (one load in flight, MFMA pipe idle ~75 % of the time)
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < MLP_MT * 16) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, h1[i / 16][i % 16], acc, 0, 0, 0);
+                } else if (i == MLP_MT * 16) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, half ? 0.0f : 1.0f, acc, 0, 0, 0);      // + b2
+                } else {                               // this h2 tile is consumed at once by the head
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b2
-            w += 64;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {             // this h2 tile is consumed at once by the head
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], fmaxf(acc[t], 0.0f), out, 0, 0, 0);
-                w += 64;
-            }
+            w += PER * 64;
         }
-        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], half ? 0.0f : 1.0f, out, 0, 0, 0);       // + b3
+        out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[0], half ? 0.0f : 1.0f, out, 0, 0, 0);             // + b3
         // action j sits in register j&3 of lane half j>>2: hand every lane all A of them
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1421,7 +1443,12 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
     ++r;
     if (r != nrec) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
     hipError_t e = hipSuccess;
-    if (!h->mlp_stream) e = hipMalloc((void **)&h->mlp_stream, (size_t)mlp_records(32) * 64 * sizeof(float));
+    // the kernel prefetches up to 29 records past the end (values unused): keep them inside the allocation
+    if (!h->mlp_stream) {
+        const size_t bytes = (size_t)(mlp_records(32) + 32) * 64 * sizeof(float);
+        e = hipMalloc((void **)&h->mlp_stream, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(h->mlp_stream, 0, bytes, (hipStream_t)stream);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)nrec * 64 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free(host);

@@ -36,6 +36,14 @@ for _ in range(T):
     env.step(pol.predict_device(env.obs), layout="aos")
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 out["mlp_torch"] = {"env_steps_per_s": B * T / dt, "us_per_step": dt / T * 1e6}
+env.set_mlp_policy([(w.astype(np.float32), b.astype(np.float32)) for w, b in ws])
+env.rollout_mlp(10)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+env.rollout_mlp(T)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+flops = 2.0 * (S * 256 + 256 * 256 + 256 * A)
+out["mlp_mfma_fused"] = {"env_steps_per_s": B * T / dt, "us_per_step": dt / T * 1e6,
+                         "actor_TFLOPs": B * T * flops / dt / 1e12}
 env.set_policy(ni.behaviour_policy(args.env, "expert"))
 env.rollout_policy(50)
 torch.cuda.synchronize(); t0 = time.perf_counter()
