@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
     ap.add_argument("--mode", default="rollout", choices=["graph", "eager", "rollout"],
                     help="graph/eager: one step kernel per env.step (step-API); rollout: fused multi-step kernel")
-    ap.add_argument("--plan-steps", type=int, default=100, help="steps recorded per hipGraph replay")
+    ap.add_argument("--plan-steps", type=int, default=250,
+                    help="env.step per launch (rollout mode) / per hipGraph replay (graph mode)")
     ap.add_argument("--ring", type=int, default=64, help="slots of the pre-filled action ring")
     ap.add_argument("--outputs", default="full", choices=["full", "min", "none"],
                     help="rollout mode: full = obs trajectory + reward + flags per step; min = reward + flags; none")
