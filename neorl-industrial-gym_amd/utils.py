@@ -63,49 +63,50 @@ def evaluate_with_safety(agent: Any, env: Any, n_episodes: int = 100, record_vid
     if isinstance(env, BatchedIndustrialEnv):
         return _evaluate_batched(agent, env, n_episodes, step_noise_fn, reset_noise_fn)
 
-    episode_returns, episode_lengths = [], []
-    total_violations = critical_violations = emergency_shutdowns = 0
-    constraint_satisfaction_rates = []
-    for _ in range(n_episodes):
-        obs, info = env.reset()
-        episode_return = 0.0
-        episode_length = episode_violations = episode_critical = episode_shutdowns = 0
-        done = False
-        while not done:
-            action = agent.predict(obs[None], deterministic=True)[0]
-            next_obs, reward, terminated, truncated, info = env.step(action)
-            done = terminated or truncated
-            episode_return += reward
-            episode_length += 1
-            if "safety_metrics" in info:
-                sm = info["safety_metrics"]
-                episode_violations += sm.violation_count
-                episode_critical += sm.critical_violations
-                constraint_satisfaction_rates.append(sm.satisfaction_rate)
-            if info.get("critical_shutdown", False):
-                episode_shutdowns += 1
-            obs = next_obs
-            if render:
-                try:
-                    env.render()
-                except Exception:
-                    pass
-        episode_returns.append(episode_return)
-        episode_lengths.append(episode_length)
-        total_violations += episode_violations
-        critical_violations += episode_critical
-        emergency_shutdowns += episode_shutdowns
+    runs = [_play_episode(agent, env, render) for _ in range(n_episodes)]
+    return _summarise(runs, n_episodes)
+
+
+def _play_episode(agent, env, render):
+    """One episode of the reference's evaluation loop (utils.py:80-118): returns
+    (return, length, sum of violation_count, sum of critical_violations, shutdown steps,
+    per-step satisfaction rates).  `ret += reward` keeps the reward's own type, as upstream."""
+    obs, _ = env.reset()
+    ret, length, viol, crit, shut, rates = 0.0, 0, 0, 0, 0, []
+    finished = False
+    while not finished:
+        obs, reward, terminated, truncated, info = env.step(agent.predict(obs[None], deterministic=True)[0])
+        finished = terminated or truncated
+        ret += reward
+        length += 1
+        sm = info.get("safety_metrics")
+        if sm is not None:
+            viol += sm.violation_count
+            crit += sm.critical_violations
+            rates.append(sm.satisfaction_rate)
+        shut += 1 if info.get("critical_shutdown", False) else 0
+        if render:
+            try:
+                env.render()
+            except Exception:
+                pass
+    return ret, length, viol, crit, shut, rates
+
+
+def _summarise(runs, n_episodes):
+    """The 13 aggregates of utils.py:128-152 from per-episode tuples."""
+    rets = [r[0] for r in runs]
+    lens = [r[1] for r in runs]
+    rates = [x for r in runs for x in r[5]]
+    viol = sum(r[2] for r in runs)
+    wins = sum(1 for x in rets if x > 0)
     return {
-        "return_mean": np.mean(episode_returns), "return_std": np.std(episode_returns),
-        "return_min": np.min(episode_returns), "return_max": np.max(episode_returns),
-        "length_mean": np.mean(episode_lengths), "length_std": np.std(episode_lengths),
-        "safety_violations": total_violations,
-        "safety_violations_per_episode": total_violations / n_episodes,
-        "critical_violations": critical_violations, "emergency_shutdowns": emergency_shutdowns,
-        "constraint_satisfaction_rate": (np.mean(constraint_satisfaction_rates)
-                                         if constraint_satisfaction_rates else 1.0),
-        "successful_episodes": sum(1 for r in episode_returns if r > 0),
-        "success_rate": sum(1 for r in episode_returns if r > 0) / n_episodes,
+        "return_mean": np.mean(rets), "return_std": np.std(rets), "return_min": np.min(rets), "return_max": np.max(rets),
+        "length_mean": np.mean(lens), "length_std": np.std(lens),
+        "safety_violations": viol, "safety_violations_per_episode": viol / n_episodes,
+        "critical_violations": sum(r[3] for r in runs), "emergency_shutdowns": sum(r[4] for r in runs),
+        "constraint_satisfaction_rate": np.mean(rates) if rates else 1.0,
+        "successful_episodes": wins, "success_rate": wins / n_episodes,
     }
 
 
