@@ -595,7 +595,7 @@ def main():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "datasets"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("datasets", "g5")):
     main()
 
 
@@ -620,3 +620,41 @@ def gen_dataset_fixtures():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "datasets":
     gen_dataset_fixtures()
+
+
+def gen_g5():
+    """G5: the G1 inputs again, but with the action handed to the reference as float64
+    (what get_dataset and the baseline agents do upstream): documents how far the float64-contaminated
+    arithmetic moves the outputs from the float32-action semantics this build pins."""
+    utils = load_reference()
+    for key, name in ENVS.items():
+        d = dict(np.load(os.path.join(OUT, f"{key}_g1.npz")))
+        n = min(1200, len(d["reward"]))
+        env = utils.make(name)
+        K = d["noise"].shape[1]
+        log = StepLog(env.state_dim, env.action_dim, K)
+        with NoiseTap(5) as tap:
+            env.reset(); tap.take()
+            for i in range(n):
+                force(env, d["state_pre"][i], int(d["step_pre"][i]), int(d["viol_pre"][i]))
+                tap.forced = list(d["noise"][i])
+                a64 = d["action"][i].astype(np.float64)
+                state_pre = env.state.copy()
+                bits = constraint_bits(env, state_pre, a64)
+                tap.take()
+                obs, reward, term, trunc, info = env.step(a64)
+                noise = tap.take(); tap.forced = None
+                sm = info["safety_metrics"]
+                log.add(state_pre=state_pre, action=d["action"][i], noise=noise, step_pre=int(d["step_pre"][i]),
+                        viol_pre=int(d["viol_pre"][i]), state_next=obs.copy(), reward=float(reward),
+                        terminated=int(bool(term)), truncated=int(bool(trunc)), viol=sm.violation_count,
+                        crit=sm.critical_violations, bits=bits, violations_after=info["violations"])
+        arr = log.arrays()
+        np.savez_compressed(os.path.join(OUT, f"{key}_g5.npz"), **arr)
+        same = (arr["state_next"].view(np.uint32) == d["state_next"][:n].view(np.uint32)).mean()
+        print(key, "g5", n, "state words identical to the float32-action run: %.4f" % same,
+              "flag mismatches:", int((arr["terminated"] != d["terminated"][:n]).sum()))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g5":
+    gen_g5()
