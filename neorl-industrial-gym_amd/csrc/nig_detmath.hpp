@@ -1,6 +1,6 @@
 // nig_detmath.hpp -- device-side deterministic math + counter-based RNG ("nig-philox-v1").
 //
-// Everything here is built from IEEE-754 + - * / sqrt only (file is compiled with
+// Everything here is built from IEEE-754 + - * / only (file is compiled with
 // -ffp-contract=off, correctly-rounded division/sqrt), so a host evaluation of the same
 // operation sequence gives the same bits.  Specification: DESIGN.md "Deterministic math"
 // and "Synthetic input generator".  None of this exists in the reference (it draws from
@@ -70,35 +70,6 @@ __device__ __forceinline__ float det_logf(float x)
     r = r + 0.693359375f * fe;
     return r;
 }
-
-// sin, cos of 2*pi*k/2^24, k a 24-bit integer: octant from the top 3 bits (exact), then
-// degree-7 / degree-8 minimax polynomials on [0, pi/4].
-__device__ __forceinline__ void det_sincos2pi_u24(uint32_t k, float &s, float &c)
-{
-    const uint32_t oct = (k >> 21) & 7u;
-    uint32_t frac = k & 0x1fffffu;
-    frac = (oct & 1u) ? (0x200000u - frac) : frac;
-    const float x = (float)frac * (0.78539816339744830962f / 2097152.0f);
-    const float z = x * x;
-    float sp = -1.9515295891e-4f;
-    sp = sp * z + 8.3321608736e-3f;
-    sp = sp * z + -1.6666654611e-1f;
-    sp = sp * z * x + x;
-    float cp = 2.443315711809948e-5f;
-    cp = cp * z + -1.388731625493765e-3f;
-    cp = cp * z + 4.166664568298827e-2f;
-    cp = cp * z * z;
-    cp = cp + -0.5f * z;
-    cp = cp + 1.0f;
-    // octants 1,2,5,6 swap sin<->cos; sign of sin: octants 4-7; sign of cos: octants 2-5
-    const bool swap = ((oct + 1u) & 2u) != 0u;
-    float ss = swap ? cp : sp;
-    float cc = swap ? sp : cp;
-    ss = (oct & 4u) ? -ss : ss;
-    cc = ((oct + 2u) & 4u) ? -cc : cc;
-    s = ss; c = cc;
-}
-
 
 // x^y for x >= 0 (x == 0 -> 0): exp(y * ln x) with the polynomials above.  Stands in for jnp's
 // float32 power in the two Advanced envs (advanced_chemical_reactor.py:301 Re**0.8,
@@ -215,42 +186,56 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 struct RngKey {
     uint32_t env_lo, env_hi, t, seed_lo, seed_hi;
+    const float4 *tab;        // the probit table staged in LDS by the kernel
     __device__ __forceinline__ u32x4 block(uint32_t stream_block) const
     {
         return philox4x32_10(env_lo, env_hi, t, stream_block, seed_lo, seed_hi);
     }
 };
 
-// two standard normals from two words: Box-Muller on 24-bit uniforms
-__device__ __forceinline__ void bm_pair(uint32_t x0, uint32_t x1, float &z0, float &z1)
+// One standard normal from one 32-bit word: piecewise-cubic inverse normal CDF.
+// Bit 31 is the sign; the next 23 bits m give the tail probability p = (m + 0.5) * 2^-24 in
+// (0, 0.5); the piece is picked by the float32 exponent and top 5 mantissa bits of f = m + 0.5
+// (24 binades x 32 = 768 pieces, narrower towards the tail), the low 18 mantissa bits are the
+// position inside the piece.  Max |error| 4.8e-7 (the float32 grid at z ~ 5); |z| <= 5.42.
+// ~17 VALU + one 16-byte LDS read, against ~43 VALU per normal for a polynomial Box-Muller
+// (log + sqrt + sincos) -- PowerGrid draws 23 normals per env-step.  The table is generated data
+// (gen_probit_table.py); the oracle compiles the same data and runs the same float32 sequence.
+__device__ const float4 NIG_PROBIT[768] = {
+#include "nig_probit_table.inc"
+};
+
+__device__ __forceinline__ float probit_normal(uint32_t word, const float4 *tab)
 {
-    const float u1 = (float)((x0 >> 8) + 1u) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * det_logf(u1));
-    float s, c;
-    det_sincos2pi_u24(x1 >> 8, s, c);
-    z0 = r * c; z1 = r * s;
+    const uint32_t v = word >> 8;
+    const float f = (float)(v & 0x7FFFFFu) + 0.5f;           // exact
+    const uint32_t b = f32_bits(f);
+    const float4 c = tab[(b >> 18) - (126u << 5)];
+    const float t = (float)(b & 0x3FFFFu) * (1.0f / 262144.0f);   // exact
+    float z = c.w * t + c.z;
+    z = z * t + c.y;
+    z = z * t + c.x;
+    return (v & 0x800000u) ? -z : z;
 }
 
 __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // exact in float32
 
 __device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
 
-// N standard normals of stream `stream` into z[0..N) (compile-time N, fully unrolled)
+// N standard normals of stream `stream` into z[0..N): one word each, four per Philox block
 template <int N>
 __device__ __forceinline__ void gen_normals(const RngKey &k, uint32_t stream, float (&z)[N])
 {
 #pragma unroll
     for (int j = 0; 4 * j < N; ++j) {
         const u32x4 x = k.block(stream + (uint32_t)j);
-        float a, b, c, d;
-        bm_pair(x.x, x.y, a, b);
-        if (4 * j + 0 < N) z[4 * j + 0] = a;
-        if (4 * j + 1 < N) z[4 * j + 1] = b;
-        if (4 * j + 2 < N) {
-            bm_pair(x.z, x.w, c, d);
-            z[4 * j + 2] = c;
-            if (4 * j + 3 < N) z[4 * j + 3] = d;
-        }
+        if (4 * j + 0 < N) z[4 * j + 0] = probit_normal(x.x, k.tab);
+        if (4 * j + 1 < N) z[4 * j + 1] = probit_normal(x.y, k.tab);
+        if (4 * j + 2 < N) z[4 * j + 2] = probit_normal(x.z, k.tab);
+        if (4 * j + 3 < N) z[4 * j + 3] = probit_normal(x.w, k.tab);
+        // one Philox block (4 table reads = 16 VGPRs of coefficients) at a time: left alone, hipcc issues
+        // the reads of all 23 PowerGrid normals up front and the kernel balloons to 186 VGPRs
+        if (N > 8) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

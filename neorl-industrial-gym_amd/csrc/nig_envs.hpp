@@ -32,6 +32,7 @@ struct ChemicalReactor {
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
+    static constexpr int STEP_WAVES = 7;          // waves per SIMD the step kernel is compiled for (no spills at this cap)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -141,6 +142,7 @@ struct PowerGrid {
     static constexpr int ID = 1, S = 32, A = 8, KS = 23, KR = 31, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~18 % of lanes finish per step (episodes of ~6 steps)
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
+    static constexpr int STEP_WAVES = 2;          // 23 fp64 noise values + 2x32 state registers: ~184 VGPRs
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -278,6 +280,7 @@ struct RobotAssembly {
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
+    static constexpr int STEP_WAVES = 5;
     using reward_t = double;
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -432,6 +435,7 @@ struct StepResult {
 struct AdvancedChemicalReactor {
     static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    static constexpr int STEP_WAVES = 5;
     using reward_t = float;    // float(total_reward) of a float32 scalar, :404
     static constexpr uint32_t CRIT_MASK = 0u;
     __device__ static constexpr float penalty(int) { return 0.0f; }
@@ -527,6 +531,7 @@ struct AdvancedChemicalReactor {
 struct AdvancedPowerGrid {
     static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    static constexpr int STEP_WAVES = 5;
     using reward_t = float;
     static constexpr uint32_t CRIT_MASK = 0u;
     __device__ static constexpr float penalty(int) { return 0.0f; }

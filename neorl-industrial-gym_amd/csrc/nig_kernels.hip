@@ -90,13 +90,21 @@ __device__ __forceinline__ uint32_t pack_flags(const StepResult<Env> &res, int s
 }
 
 // Per-lane key of the counter-based generator: (global env index, launch counter t).
-__device__ __forceinline__ RngKey make_key(uint64_t gi, uint32_t t, uint32_t seed_lo, uint32_t seed_hi)
+__device__ __forceinline__ RngKey make_key(uint64_t gi, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
+                                           const float4 *tab = nullptr)
 {
     RngKey k;
     k.env_lo = (uint32_t)gi; k.env_hi = (uint32_t)(gi >> 32);
-    k.t = t; k.seed_lo = seed_lo; k.seed_hi = seed_hi;
+    k.t = t; k.seed_lo = seed_lo; k.seed_hi = seed_hi; k.tab = tab;
     return k;
 }
+
+// Stage the 12 KiB probit table (normal transform of the generator) in LDS.  Every thread of the block
+// must pass through here before any early exit.
+#define NIG_STAGE_PROBIT(tab)                                                         \
+    __shared__ float4 tab[768];                                                       \
+    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) tab[i_] = NIG_PROBIT[i_];  \
+    __syncthreads()
 
 // Episode bookkeeping of one finished episode (utils.py:120-125), lane-private column of the tally.
 // All 11 rows are loaded before any is stored: one memory round trip instead of eleven dependent ones.
@@ -176,7 +184,7 @@ struct LaneTally {
 // PowerGrid lanes finishing per step every wave would otherwise run the whole reset path for a
 // handful of active lanes).
 template <class Env, bool PARITY>
-__global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
+__global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const StepArgs p)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
@@ -217,9 +225,11 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
             for (int k = 0; k < KS; ++k) nz[k] = 0.0;
         }
     }
+    // stage the generator's table only now: the state/action loads above are already in flight
+    NIG_STAGE_PROBIT(s_probit);
     const bool active = in_range && !(ctr & NIG_CTR_DONE);     // base.py:159-160: finished lanes wait for reset
 
-    const RngKey key = make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi);
+    const RngKey key = make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, s_probit);
     if constexpr (KS > 0) {
         if constexpr (!PARITY) Env::draw_step(key, nz);
     } else {
@@ -294,7 +304,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
 #pragma unroll
             for (int k = 0; k < KR; ++k) rn[k] = (rn_row + k * p.ld_noise)[tl];
         } else {
-            Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_now, p.seed_lo, p.seed_hi), rn);
+            Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_now, p.seed_lo, p.seed_hi, s_probit), rn);
         }
         float r0[S];
         Env::init(rn, r0);
@@ -334,7 +344,6 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
-    using R = typename Env::reward_t;
     // Envs whose episodes are short (PowerGrid ~6 steps, RobotAssembly: most waves see a reset
     // every step) compact the finishing lanes of the 256-lane block through LDS each step and let
     // ONE wave produce all their initial states at full lane utilisation; the owners read them
@@ -346,6 +355,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     __shared__ float s_init[COMPACT ? S * BLOCK : 1];
     __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
     __shared__ int s_cnt[COMPACT ? NWAVE : 1];
+    NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
@@ -391,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const uint32_t orow = (uint32_t)it * q.out_stride;
         const bool frozen = (ctr & NIG_CTR_DONE) != 0;             // no auto-reset: base.py:159-160
-        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
                 for (int qq = 0; qq < NWAVE - 1; ++qq) { const bool nxt = (w == qq) && (r >= cnt[qq]); r = nxt ? r - cnt[qq] : r; w = nxt ? qq + 1 : w; }
                 const unsigned tl = s_list[w * 64 + r];
                 double rn[KR > 0 ? KR : 1];
-                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi), rn);
+                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tl), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit), rn);
                 float r0[S];
                 Env::init(rn, r0);
 #pragma unroll
@@ -595,7 +605,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
-    using R = typename Env::reward_t;
+    NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
@@ -623,7 +633,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
             if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
             continue;
         }
-        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         policy_action<Env>(q.pol, s, key, integ, eprev, a);
         if (q.obs_out) {
             float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) + (size_t)(base + tid) * (S / 4);
@@ -711,6 +721,7 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     static_assert(S % 2 == 0 && A <= 8, "MFMA actor needs an even state dim and at most 8 actions");
+    NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
     const uint32_t lane0 = blockIdx.x * (BLOCK / 2) + (tid >> 6) * 32u;     // first env of this wave
@@ -817,7 +828,7 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
                 for (int j = 0; j < A; ++j) (ao + j * q.ld_act_out)[li] = a[j];
             }
         }
-        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi);
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
@@ -880,6 +891,7 @@ template <class Env, bool PARITY>
 __global__ void __launch_bounds__(BLOCK) reset_kernel(const ResetArgs p)
 {
     constexpr int S = Env::S, KR = Env::KR;
+    NIG_STAGE_PROBIT(s_probit);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= p.B) return;
     if (p.mask && !p.mask[i]) return;
@@ -888,7 +900,7 @@ __global__ void __launch_bounds__(BLOCK) reset_kernel(const ResetArgs p)
 #pragma unroll
         for (int k = 0; k < KR; ++k) rn[k] = p.noise[(int64_t)k * p.ld_noise + i];
     } else {
-        Env::draw_init(make_key(p.env0 + (uint64_t)i, p.t, p.seed_lo, p.seed_hi), rn);
+        Env::draw_init(make_key(p.env0 + (uint64_t)i, p.t, p.seed_lo, p.seed_hi, s_probit), rn);
     }
     float s[S];
     Env::init(rn, s);

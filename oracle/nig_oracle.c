@@ -33,7 +33,7 @@
 #define MATH_POLY 1 /* documented polynomials (DESIGN.md "detmath"), bitwise = device */
 
 /* ------------------------------------------------------------------------------
- * detmath: polynomial exp/log/sincos written ONLY with IEEE + - * / (no fma, no
+ * detmath: polynomial exp/log/sincos/pow/tanh written ONLY with IEEE + - * / (no fma, no
  * libm) so that a CPU and a GPU evaluation agree bit-for-bit.  Specification in
  * DESIGN.md section "Deterministic math".  Coefficients are the classic Cephes
  * single-precision / fdlibm double-precision minimax sets.
@@ -89,38 +89,6 @@ static float det_logf(float x)
     float r = m + y;
     r = r + 0.693359375f * fe;
     return r;
-}
-
-/* sin and cos of 2*pi*k/2^24 for a 24-bit integer k (exact octant reduction) */
-static void det_sincos2pi_u24(uint32_t k, float *s, float *c)
-{
-    uint32_t oct = (k >> 21) & 7u;
-    uint32_t frac = k & 0x1fffffu;
-    if (oct & 1u) frac = 0x200000u - frac;           /* reflect inside odd octants */
-    float x = (float)frac * (0.78539816339744830962f / 2097152.0f); /* [0, pi/4] */
-    float z = x * x;
-    float sp = -1.9515295891e-4f;
-    sp = sp * z + 8.3321608736e-3f;
-    sp = sp * z + -1.6666654611e-1f;
-    sp = sp * z * x + x;
-    float cp = 2.443315711809948e-5f;
-    cp = cp * z + -1.388731625493765e-3f;
-    cp = cp * z + 4.166664568298827e-2f;
-    cp = cp * z * z;
-    cp = cp + -0.5f * z;
-    cp = cp + 1.0f;
-    float ss, cc;
-    switch (oct) {
-    case 0: ss = sp;  cc = cp;  break;
-    case 1: ss = cp;  cc = sp;  break;
-    case 2: ss = cp;  cc = -sp; break;
-    case 3: ss = sp;  cc = -cp; break;
-    case 4: ss = -sp; cc = -cp; break;
-    case 5: ss = -cp; cc = -sp; break;
-    case 6: ss = -cp; cc = sp;  break;
-    default: ss = -sp; cc = cp; break;
-    }
-    *s = ss; *c = cc;
 }
 
 /* double sin/cos for moderate |x| (joint angles, |x| <= ~1e3): Cody-Waite + fdlibm kernels */
@@ -790,30 +758,37 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 #define STREAM_RESET 0x40000000u
 #define STREAM_ACTION 0x80000000u
 
-/* two standard normals from two u32 (Box-Muller on 24-bit uniforms, detmath) */
-static void bm_pair(uint32_t x0, uint32_t x1, float *z0, float *z1)
+/* One standard normal per 32-bit word: piecewise-cubic inverse normal CDF over generated data
+ * (nig_probit_table.inc, see neorl-industrial-gym_amd/csrc/gen_probit_table.py): bit 31 = sign,
+ * next 23 bits m -> f = m + 0.5; piece = f's float32 exponent and top 5 mantissa bits, position =
+ * low 18 mantissa bits; z = c0 + t(c1 + t(c2 + t c3)) in float32, one rounding per operation. */
+static const float PROBIT[768][4] = {
+#include "nig_probit_table.inc"
+};
+
+static float probit_normal(uint32_t word)
 {
-    float u1 = (float)((x0 >> 8) + 1u) * (1.0f / 16777216.0f);     /* (0, 1] */
-    float r = sqrtf(-2.0f * det_logf(u1));
-    float s, c;
-    det_sincos2pi_u24(x1 >> 8, &s, &c);
-    *z0 = r * c; *z1 = r * s;
+    uint32_t v = word >> 8;
+    union { float f; uint32_t u; } q;
+    q.f = (float)(v & 0x7FFFFFu) + 0.5f;
+    const float *c = PROBIT[(q.u >> 18) - (126u << 5)];
+    float t = (float)(q.u & 0x3FFFFu) * (1.0f / 262144.0f);
+    float z = c[3] * t + c[2];
+    z = z * t + c[1];
+    z = z * t + c[0];
+    return (v & 0x800000u) ? -z : z;
 }
 
 static double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }  /* [0,1) */
 
-/* n standard normals for (env_index, t) on a stream */
+/* n standard normals for (env_index, t) on a stream: one word each, four per Philox block */
 static void gen_normals(uint64_t seed, uint64_t env_index, uint32_t t, uint32_t stream, int n, float *z)
 {
     uint32_t x[4];
     for (int j = 0; 4 * j < n; j++) {
         philox4x32_10((uint32_t)env_index, (uint32_t)(env_index >> 32), t, stream + (uint32_t)j,
                       (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        float a, b, c, d;
-        bm_pair(x[0], x[1], &a, &b);
-        bm_pair(x[2], x[3], &c, &d);
-        float q[4] = {a, b, c, d};
-        for (int i = 0; i < 4 && 4 * j + i < n; i++) z[4 * j + i] = q[i];
+        for (int i = 0; i < 4 && 4 * j + i < n; i++) z[4 * j + i] = probit_normal(x[i]);
     }
 }
 
@@ -1195,7 +1170,7 @@ void oracle_policy_action(int env, const oracle_policy_t *P, const float *obs, u
 /* exposed for unit tests of the math layer */
 float oracle_det_expf(float x) { return det_expf(x); }
 float oracle_det_logf(float x) { return det_logf(x); }
-void oracle_det_sincos2pi_u24(uint32_t k, float *s, float *c) { det_sincos2pi_u24(k, s, c); }
+float oracle_probit_normal(uint32_t word) { return probit_normal(word); }
 void oracle_det_sincos(double x, double *s, double *c) { det_sincos(x, s, c); }
 void oracle_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
 {
