@@ -43,7 +43,7 @@ __device__ __forceinline__ float det_expf(float x)
     return res;
 }
 
-// ln(x) for a positive normal float (Box-Muller passes k*2^-24, k >= 1; det_powf any x > 0).
+// ln(x) for a positive normal float (used by det_powf).
 __device__ __forceinline__ float det_logf(float x)
 {
     const uint32_t u = f32_bits(x);
