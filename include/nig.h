@@ -304,6 +304,21 @@ int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t 
                     int64_t out_stride, float *obs_out, int64_t obs_step_stride,
                     float *act_out, int64_t ld_act, int64_t act_step_stride, void *stream);
 
+/*
+ * Host-buffer forms for SMALL batches -- the single-env drop-in classes (env.reset() / env.step()
+ * return NumPy arrays, base.py:133-213).  Inputs are host arrays, results are copied back to host
+ * arrays; the library stages through pinned memory it owns and synchronises `stream` once before
+ * returning.  PCIe-/launch-latency bound by construction (tens of microseconds per call); use the
+ * device-pointer entry points above for throughput.
+ *   actions     float  [A][B] host            step_noise  double [k_step][B] host or NULL (fast mode)
+ *   init_noise  double [k_reset][B] host or NULL
+ *   state_out   float  [S][B] host (new state == observation)
+ *   reward64_out double [B] host,  flags_out uint32 [B] host
+ */
+int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, void *stream);
+int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out,
+                  double *reward64_out, uint32_t *flags_out, void *stream);
+
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);

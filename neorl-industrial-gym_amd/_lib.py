@@ -6,6 +6,12 @@ The extension is mandatory: importing this module without a built libnig.so rais
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (libamdhip64).  It must be in the process BEFORE libnig.so is
+# loaded so that libnig.so binds to that same runtime: with the opposite order the loader pulls the
+# system ROCm copy for libnig.so, two runtimes coexist, and the second one to initialise reports
+# "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 from . import _build
 
 NIG_OK = 0
@@ -22,7 +28,7 @@ SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
     "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
-    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp",
+    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
 ]
 
 
@@ -101,6 +107,8 @@ def lib():
     L.nig_rollout_policy.argtypes = [vp, i32, vp, vp, i64, vp, i64, vp, i64, i64, vp]
     L.nig_set_mlp_policy.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.nig_rollout_mlp.argtypes = [vp, i32, vp, vp, i64, vp, i64, vp, i64, i64, vp]
+    L.nig_reset_host.argtypes = [vp, vp, vp, vp]
+    L.nig_step_host.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.nig_rollout.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
     _lib = L
     return L

@@ -72,11 +72,11 @@ class Box:
         self.shape = tuple(np.shape(low)) if shape is None else tuple(shape)
         self.low = np.broadcast_to(np.asarray(low, dtype=self.dtype), self.shape).copy()
         self.high = np.broadcast_to(np.asarray(high, dtype=self.dtype), self.shape).copy()
+        self._lo = np.where(np.isfinite(self.low), self.low, -1e6).astype(np.float64)
+        self._hi = np.where(np.isfinite(self.high), self.high, 1e6).astype(np.float64)
 
     def sample(self):
-        lo = np.where(np.isfinite(self.low), self.low, -1e6)
-        hi = np.where(np.isfinite(self.high), self.high, 1e6)
-        return np.random.uniform(lo, hi).astype(self.dtype)
+        return np.random.uniform(self._lo, self._hi).astype(self.dtype)
 
     def contains(self, x) -> bool:
         x = np.asarray(x)

@@ -1033,6 +1033,9 @@ struct nig_handle {
     nig_policy pol_host;   // staging copy (must outlive the async H2D copy)
     bool has_policy;
     float *mlp_stream;     // device copy of the MFMA operand stream of the MLP actor (owned)
+    char *hst_pinned;      // host-buffer entry points: pinned staging + its device mirror (owned, lazy)
+    char *hst_dev;
+    size_t hst_bytes;
 };
 
 struct nig_plan {
@@ -1220,7 +1223,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
     h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false; h->mlp_stream = nullptr;
+    h->has_policy = false; h->mlp_stream = nullptr; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -1243,6 +1246,8 @@ int nig_destroy(nig_handle *h)
 {
     if (!h) return NIG_OK;
     if (h->mlp_stream) (void)hipFree(h->mlp_stream);
+    if (h->hst_dev) (void)hipFree(h->hst_dev);
+    if (h->hst_pinned) (void)hipHostFree(h->hst_pinned);
     if (h->owns_ws && h->ws) (void)hipFree(h->ws);
     delete h;
     return NIG_OK;
@@ -1495,6 +1500,97 @@ int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t 
     NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_mlp_kernel<E>), dim3(grid), dim3(BLOCK), 0, st, q));
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
+    return NIG_OK;
+}
+
+// ---- host-buffer entry points (small batches) -------------------------------------------------
+// staging layout (same on host and device): [actions f32 A*B][noise f64 K*B] | [state f32 S*B][reward64 f64 B][flags u32 B]
+// (uploads = the first part, downloads = the second part: one memcpy each way)
+struct HostStage { size_t off_act, off_noise, off_state, off_rew, off_flags, bytes; };
+
+static HostStage host_stage_layout(const nig_handle *h)
+{
+    const nig_env_spec &sp = SPECS[h->env];
+    const size_t B = (size_t)h->B;
+    const size_t K = (size_t)(sp.k_step > sp.k_reset ? sp.k_step : sp.k_reset);
+    HostStage L;
+    L.off_act = 0;
+    L.off_noise = (size_t)align_up((int64_t)(sp.action_dim * B * 4), 256);
+    L.off_state = L.off_noise + (size_t)align_up((int64_t)(K * B * 8), 256);
+    L.off_rew = L.off_state + (size_t)align_up((int64_t)(sp.state_dim * B * 4), 256);
+    L.off_flags = L.off_rew + (size_t)align_up((int64_t)(B * 8), 256);
+    L.bytes = L.off_flags + (size_t)align_up((int64_t)(B * 4), 256);
+    return L;
+}
+
+static int host_stage_ensure(nig_handle *h, const HostStage &L)
+{
+    if (h->hst_pinned && h->hst_bytes >= L.bytes) return NIG_OK;
+    if (h->B > 65536) return fail(NIG_ERR_UNSUPPORTED, "host-buffer entry points are for small batches (<= 65536 lanes)%s");
+    if (h->hst_dev) { (void)hipFree(h->hst_dev); h->hst_dev = nullptr; }
+    if (h->hst_pinned) { (void)hipHostFree(h->hst_pinned); h->hst_pinned = nullptr; }
+    HIP_TRY(hipHostMalloc((void **)&h->hst_pinned, L.bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&h->hst_dev, L.bytes));
+    h->hst_bytes = L.bytes;
+    return NIG_OK;
+}
+
+int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, void *stream)
+{
+    if (!h || !state_out) return fail(NIG_ERR_INVALID, "nig_reset_host: NULL argument%s");
+    const nig_env_spec &sp = SPECS[h->env];
+    const HostStage L = host_stage_layout(h);
+    int rc = host_stage_ensure(h, L);
+    if (rc != NIG_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = (size_t)h->B;
+    const double *dn = nullptr;
+    if (init_noise && sp.k_reset > 0) {
+        memcpy(h->hst_pinned + L.off_noise, init_noise, (size_t)sp.k_reset * B * 8);
+        HIP_TRY(hipMemcpyAsync(h->hst_dev + L.off_noise, h->hst_pinned + L.off_noise, (size_t)sp.k_reset * B * 8, hipMemcpyHostToDevice, st));
+        dn = (const double *)(h->hst_dev + L.off_noise);
+    }
+    rc = nig_reset(h, nullptr, dn, (int64_t)B, stream);
+    if (rc != NIG_OK) return rc;
+    // gather the rows (ld apart on the device) into the contiguous staging image, then ONE download
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
+                       (float *)(h->hst_dev + L.off_state), (int64_t)B, sp.state_dim, h->B);
+    HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, (size_t)sp.state_dim * B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);
+    return NIG_OK;
+}
+
+int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out, double *reward64_out,
+                  uint32_t *flags_out, void *stream)
+{
+    if (!h || !actions || !state_out || !reward64_out || !flags_out) return fail(NIG_ERR_INVALID, "nig_step_host: NULL argument%s");
+    const nig_env_spec &sp = SPECS[h->env];
+    const HostStage L = host_stage_layout(h);
+    int rc = host_stage_ensure(h, L);
+    if (rc != NIG_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = (size_t)h->B;
+    memcpy(h->hst_pinned + L.off_act, actions, (size_t)sp.action_dim * B * 4);
+    size_t up = (size_t)sp.action_dim * B * 4;
+    const double *dn = nullptr;
+    if (step_noise && sp.k_step > 0) {
+        memcpy(h->hst_pinned + L.off_noise, step_noise, (size_t)sp.k_step * B * 8);
+        up = L.off_noise + (size_t)sp.k_step * B * 8;          // one contiguous upload covers both
+        dn = (const double *)(h->hst_dev + L.off_noise);
+    }
+    HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
+    rc = nig_step(h, (const float *)(h->hst_dev + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
+                  (double *)(h->hst_dev + L.off_rew), (uint32_t *)(h->hst_dev + L.off_flags), nullptr, 0, stream);
+    if (rc != NIG_OK) return rc;
+    // state rows gathered next to reward64 and flags: one download for everything the call returns
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
+                       (float *)(h->hst_dev + L.off_state), (int64_t)B, sp.state_dim, h->B);
+    HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, L.bytes - L.off_state, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);
+    memcpy(reward64_out, h->hst_pinned + L.off_rew, B * 8);
+    memcpy(flags_out, h->hst_pinned + L.off_flags, B * 4);
     return NIG_OK;
 }
 

@@ -49,8 +49,17 @@ class IndustrialEnv:
         self.observation_space = self._b.observation_space                             # base.py:60-72
         self.action_space = self._b.action_space
         self._last_metrics: Optional[SafetyMetrics] = None
-        self._state_host = torch.empty(1, self.state_dim, dtype=torch.float32).pin_memory()
         self._needs_reset = True
+        self._sig, self._mask, self._custom = None, 0, []
+        # host-side I/O buffers of the host-buffer ABI (nig_reset_host / nig_step_host): no torch op per step
+        import ctypes as C
+        self._C = C
+        self._st_buf = np.zeros((self.state_dim, 1), dtype=np.float32)
+        self._act_buf = np.zeros((self.action_dim, 1), dtype=np.float32)
+        self._rew_buf = np.zeros(1, dtype=np.float64)
+        self._fl_buf = np.zeros(1, dtype=np.uint32)
+        self._p_st, self._p_act = self._st_buf.ctypes.data_as(C.c_void_p), self._act_buf.ctypes.data_as(C.c_void_p)
+        self._p_rew, self._p_fl = self._rew_buf.ctypes.data_as(C.c_void_p), self._fl_buf.ctypes.data_as(C.c_void_p)
 
     # -- per-env host pieces (overridden) --------------------------------------
     def _builtin_constraints(self) -> List[SafetyConstraint]:
@@ -68,19 +77,22 @@ class IndustrialEnv:
 
     # -- helpers ---------------------------------------------------------------
     def _pull_state(self) -> np.ndarray:
-        self._state_host.copy_(self._b.obs)          # D2H of S floats (synchronises the stream)
-        return self._state_host.numpy()[0].copy()
+        return self._b.obs.cpu().numpy()[0].copy()   # out-of-band read (teacher forcing in tests)
 
     def _sync_constraint_mask(self):
-        names = {c.name for c in self.safety_constraints}
-        mask = 0
-        for k, c in enumerate(self._builtin):
-            # a built-in stays on the device only while the identical object is still in the list
-            if any(c is x for x in self.safety_constraints):
-                mask |= 1 << k
-        del names
-        self._b.set_constraint_mask(mask)
-        return mask
+        """Device mask of the built-ins still in the list + the user-added constraints (host-evaluated).
+        Recomputed only when the list changed."""
+        sig = tuple(map(id, self.safety_constraints))
+        if sig != self._sig:
+            mask = 0
+            for k, c in enumerate(self._builtin):
+                # a built-in stays on the device only while the identical object is still in the list
+                if any(c is x for x in self.safety_constraints):
+                    mask |= 1 << k
+            self._b.set_constraint_mask(mask)
+            self._sig, self._mask = sig, mask
+            self._custom = [c for c in self.safety_constraints if not any(c is b for b in self._builtin)]
+        return self._mask
 
     # -- API -------------------------------------------------------------------
     def reset(self, *, seed: Optional[int] = None, options: Optional[Dict] = None) -> Tuple[np.ndarray, Dict]:
@@ -89,12 +101,12 @@ class IndustrialEnv:
         self.current_step = 0
         self.done = False
         self.violation_count = 0
+        nz = None
         if self._noise_mode == "numpy":
-            nz = self._draw_reset_noise().reshape(-1, 1)
-            self._b.reset(init_noise=nz)
-        else:
-            self._b.reset()
-        self.state = self._pull_state()
+            nz = np.ascontiguousarray(self._draw_reset_noise(), dtype=np.float64)
+        _lib.check(self._b._L.nig_reset_host(self._b._h, None if nz is None or nz.size == 0 else nz.ctypes.data_as(self._C.c_void_p),
+                                             self._p_st, None))
+        self.state = self._st_buf[:, 0].copy()
         self._needs_reset = False
         obs = self.state.copy()
         info = self._get_safety_info(self.state)
@@ -111,17 +123,19 @@ class IndustrialEnv:
         a_clip = a32 if self._no_clip else np.clip(a32, self.action_space.low, self.action_space.high)   # base.py:167
         state_pre = self.state
         mask = self._sync_constraint_mask()
-        custom = [c for c in self.safety_constraints if not any(c is b for b in self._builtin)]
+        custom = self._custom
 
         sn = None
         if self._noise_mode == "numpy":
             sn = self._draw_step_noise()
-            sn = None if sn is None else sn.reshape(-1, 1)
-        # parity mode without step noise (RobotAssembly draws none): still deterministic
-        self._b.step(torch.from_numpy(a32.reshape(self.action_dim, 1)), step_noise=sn, layout="soa")
-        new_state = self._pull_state()
-        flags = int(self._b.flags.item())
-        reward64 = float(self._b.reward64.item())
+            sn = None if sn is None else np.ascontiguousarray(sn, dtype=np.float64)
+        # one call: upload action (+ noise), step kernel, download state / reward / flag word, one sync
+        self._act_buf[:, 0] = a32
+        _lib.check(self._b._L.nig_step_host(self._b._h, self._p_act, None if sn is None else sn.ctypes.data_as(self._C.c_void_p),
+                                            self._p_st, self._p_rew, self._p_fl, None))
+        new_state = self._st_buf[:, 0].copy()
+        flags = int(self._fl_buf[0])
+        reward64 = float(self._rew_buf[0])
         reward: Any = f32(reward64) if int(self._b.spec.reward_is_f32) else reward64
 
         nv = ((flags >> _lib.FLAG_NVIOL_SHIFT) & 3) + ((flags >> 13) & 1) * 4
@@ -366,7 +380,7 @@ class _AdvancedEnv(IndustrialEnv):
 
     def step(self, action):
         obs, reward, terminated, truncated, info = super().step(action)
-        fl = int(self._b.flags.item())
+        fl = int(self._fl_buf[0])
         names = [n for k, n in enumerate(self._VIOLATIONS) if (fl >> (2 + k if k < 3 else 12)) & 1]
         info["violation_types"] = names
         info.update(self._extra_info(obs, action, fl))
