@@ -370,7 +370,6 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
 
     uint32_t ctr = in_range ? (p.ctr + base)[tid] : (uint32_t)NIG_CTR_DONE;   // out-of-range lanes idle as "frozen"
     float s[S], a[A], n[S];
-    double nz[KSN];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld_state)[tid] : 0.0f;
     double ret = (tally && in_range) ? (p.ep_ret + base)[tid] : 0.0;
@@ -396,13 +395,22 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     // waits sized for the first one.
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
-    auto one_step = [&](float (&abuf)[A], const int it) __attribute__((always_inline)) {
+    // Process noise is produced one step AHEAD (ping-pong sets nzA/nzB like the action buffers): the
+    // Philox rounds and the LDS table reads of step it+1 are issued in the shadow of step it's stores
+    // instead of sitting, un-overlapped, at the head of the step that consumes them.
+    // (only for envs with a few draws per step: two sets of PowerGrid's 23 fp64 values would cost 92 VGPRs)
+    constexpr bool LOOKAHEAD = (KS > 0 && KS <= 4);
+    double nzA[KSN], nzB[KSN];
+    if constexpr (LOOKAHEAD) Env::draw_step(make_key(gi, t_base + 1u, p.seed_lo, p.seed_hi, s_probit), nzA);
+    else { nzA[0] = 0.0; nzB[0] = 0.0; }
+
+    auto one_step = [&](float (&abuf)[A], double (&nz)[KSN], double (&nz_next)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const uint32_t orow = (uint32_t)it * q.out_stride;
         const bool frozen = (ctr & NIG_CTR_DONE) != 0;             // no auto-reset: base.py:159-160
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
-        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        if constexpr (KS > 0 && !LOOKAHEAD) Env::draw_step(key, nz);
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
@@ -432,6 +440,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
             const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
             for (int k = 0; k < A; ++k) abuf[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
+        }
+        if constexpr (LOOKAHEAD) {                 // next step's noise (keyed by t+1), see above
+            Env::draw_step(make_key(gi, t_base + (uint32_t)it + 2u, p.seed_lo, p.seed_hi, s_probit), nz_next);
+            __builtin_amdgcn_sched_barrier(0);     // keep it here: hipcc would sink it back to its consumer
         }
         if (in_range) {
         if constexpr (OUT == 3) {
@@ -502,10 +514,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     // with them the wait for the freshest loads) on the back edge
     int it = 0;
     for (; it + 1 < q.n_steps; it += 2) {
-        one_step(bufA, it);
-        one_step(bufB, it + 1);
+        one_step(bufA, nzA, nzB, it);
+        one_step(bufB, nzB, nzA, it + 1);
     }
-    if (it < q.n_steps) one_step(bufA, it);
+    if (it < q.n_steps) one_step(bufA, nzA, nzB, it);
     if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
