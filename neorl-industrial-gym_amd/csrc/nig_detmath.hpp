@@ -12,6 +12,22 @@
 
 namespace nig {
 
+// x / c for a compile-time constant c, correctly rounded like the true division NumPy does, in 4 VALU
+// instead of the ~11 of the generic sequence: q0 = RN(x * RN(1/c)), r = x - c*q0 (exact in one fma),
+// q = RN(q0 + r * RN(1/c)) (Markstein's correction).  For a given c the result depends only on the
+// significand of x, so tests/test_host_logic.py proves each constant used here exhaustively over all
+// 2^23 significands (tests/constdiv_check.c); v_div_fixup restores the IEEE special cases (signed
+// zero, inf, NaN).  Valid while neither x*RN(1/c) nor the residual leaves the normal range
+// (2^-100 < |x| < 2^100 is ample); every call site divides a physical quantity far inside that.
+__device__ __forceinline__ float fdiv_c(float x, const float c)
+{
+    const float rc = 1.0f / c;                    // folded at compile time (c is a literal at every call site)
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-c, q0, x);
+    const float q = __builtin_fmaf(r, rc, q0);
+    return __builtin_amdgcn_div_fixupf(q, c, x);
+}
+
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
 

@@ -88,10 +88,10 @@ struct ChemicalReactor {
         const float hp = manual ? a[0] * 50000.0f : -10000.0f;          // :127 / :132
         const float cadj = manual ? a[1] * 0.1f : 0.1f;                 // :128 / :133
         const float fadj = manual ? a[2] * 0.1f : -0.1f;                // :129 / :134
-        const float kc = (0.1f * conc) * (cat / 100.0f);                // shared prefix of :137-139 and :175-177
+        const float kc = (0.1f * conc) * fdiv_c(cat, 100.0f);                // shared prefix of :137-139 and :175-177
         const float rh = kc * 10000.0f;
         const float ch = ((cool * 100.0f) * (T - hx)) * 0.1f;           // :141
-        float dT = ((hp + rh) - ch) / 418000.0f;                        // :143-146 (4.18e3*1000*0.1 -> f32)
+        float dT = fdiv_c((hp + rh) - ch, 418000.0f);                        // :143-146 (4.18e3*1000*0.1 -> f32)
         dT = dT + (float)nz[0];                                         // :149
         const float nT = T + dT * 0.1f;                                 // :151
         float nP = P * (nT / T) + ((conc * 0.1f) * 1000.0f) * 0.1f;     // :155-158
@@ -100,7 +100,7 @@ struct ChemicalReactor {
         if (nrel > 0.0f) nP = pymax(101325.0f, nP - (nrel * 0.01f) * 10000.0f);              // :166-168
         const float ncool = pymax(10.0f, pymin(100.0f, cool + cadj));   // :171
         const float nfeed = pymax(5.0f, pymin(50.0f, feed + fadj));     // :172
-        const float rr = kc * det_expf((-(nT - 320.0f)) / 20.0f);       // :175-178
+        const float rr = kc * det_expf(fdiv_c(-(nT - 320.0f), 20.0f));       // :175-178
         const float nconc = pymax(0.0f, conc + (rr - nfeed * 0.001f) * 0.1f);   // :180-182
         const float ncat = pymax(50.0f, cat - ((nT > 340.0f) ? 0.001f : 0.0001f)); // :185-186
         const float nhx = hx + (0.1f * ((290.0f + cool * 0.1f) - hx)) * 0.1f;   // :189-190
@@ -118,8 +118,8 @@ struct ChemicalReactor {
     {
         float r = n[4] * 100.0f;                                        // 0.0 + x == x, :242
         r = r - fabsf(n[0] - 320.0f) * 0.5f;                            // :245-246
-        r = r - (fabsf(n[1] - 253312.5f) / 1000.0f) * 0.1f;             // :249-250
-        r = r + (n[5] / 100.0f) * 10.0f;                                // :253
+        r = r - fdiv_c(fabsf(n[1] - 253312.5f), 1000.0f) * 0.1f;             // :249-250
+        r = r + fdiv_c(n[5], 100.0f) * 10.0f;                                // :253
         const bool band = (30.0f <= n[10]) && (n[10] <= 80.0f);         // :256
         r = band ? (r + 5.0f) : (r - fabsf(n[10] - 55.0f) * 0.2f);      // :257-259
         r = (n[9] > 0.5f) ? (r - 50.0f) : r;                            // :262-263
@@ -230,7 +230,7 @@ struct PowerGrid {
             load[i] = s[17 + i];
         }
         const float imb = sum8(ngen) - sum8(load);                       // :127-129
-        const float fd = ((-1.0f * s[0]) + imb) / 5.0f;                  // :132
+        const float fd = fdiv_c((-1.0f * s[0]) + imb, 5.0f);                  // :132
         o[0] = s[0] + fd * dt;                                           // :133
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -476,39 +476,39 @@ struct AdvancedChemicalReactor {
 #pragma unroll
         for (int i = 0; i < 4; ++i) Qw = Qw + 6044.969827561761f * (T - s[12 + i]);   // :246-250
         const float Qf = ((nFf * 1000.0f) * 4180.0f) * (a[3] - T);       // :253
-        const float dTr = (((Qgen - Qj) - Qw) + Qf) / 4180000.0f;        // :256-259
-        const float dTj = (Qj - ((nFc * 1000.0f) * 4180.0f) * (Tj - 293.15f)) / 418000.0f;   // :262-266
+        const float dTr = fdiv_c(((Qgen - Qj) - Qw) + Qf, 4180000.0f);        // :256-259
+        const float dTj = fdiv_c(Qj - ((nFc * 1000.0f) * 4180.0f) * (Tj - 293.15f), 418000.0f);   // :262-266
         float nTw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                    // :269-280
             const float w = s[12 + i];
-            const float wd = (5000.0f * (T - w) - 10.0f * (w - 293.15f)) / 25000.0f;
+            const float wd = fdiv_c(5000.0f * (T - w) - 10.0f * (w - 293.15f), 25000.0f);
             nTw[i] = w + dt * wd;
         }
         const float moles = (((cA + cB) + cC) + cD) * 1.0f;              // :284
         const float vp = 1000.0f * det_expf(20.0f - 5000.0f / T);        // :287
         float nP = ((((8.314f * T) * moles) / 1.0f) + vp) + 1e5f;        // :290-292
-        if (nP > 2400000.0f) nP = nP - (a[4] / 100.0f) * (nP - 2400000.0f);   // :295-297 (3e6*0.8)
-        const float nmix = det_tanhf(rpm / 1000.0f) * 0.9f + 0.1f;       // :300
-        const float Re = ((rpm * 0.1f) * 1000.0f) / 0.001f;              // :301
+        if (nP > 2400000.0f) nP = nP - fdiv_c(a[4], 100.0f) * (nP - 2400000.0f);   // :295-297 (3e6*0.8)
+        const float nmix = det_tanhf(fdiv_c(rpm, 1000.0f)) * 0.9f + 0.1f;       // :300
+        const float Re = fdiv_c((rpm * 0.1f) * 1000.0f, 0.001f);              // :301
         const float Nu = 0.023f * det_powf(Re, 0.8f);                    // :302
-        const float nhc = (Nu * 0.6f) / 0.1f;                            // :303
+        const float nhc = fdiv_c(Nu * 0.6f, 0.1f);                            // :303
         const float nFp = 0.001f * (1.0f + 0.5f * ((nP - 1e5f) / 1e5f)); // :306-307
         const float nA = fmaxf(0.0f, cA + dt * dA), nB = fmaxf(0.0f, cB + dt * dB);   // :310-313
         const float nC = fmaxf(0.0f, cC + dt * dC), nD = fmaxf(0.0f, cD + dt * dD);
         const float nT = T + dt * dTr, nTj = Tj + dt * dTj;              // :315-316
         const float tau = 1.0f / fmaxf(nFp, 1e-6f);                      // :319
         const float conv = (2.0f - nA) / 2.0f;                           // :322-323
-        const float mT = ((673.15f - nT) / 673.15f) * 100.0f;            // :326
+        const float mT = fdiv_c(673.15f - nT, 673.15f) * 100.0f;            // :326
         const float mP = ((5e6f - nP) / 5e6f) * 100.0f;                  // :327
         o[0] = nT; o[1] = nTj; o[2] = nP; o[3] = nA; o[4] = nB; o[5] = nC; o[6] = nD;
         o[7] = nFf; o[8] = nFp; o[9] = nFc; o[10] = nhc; o[11] = nmix;
         o[12] = nTw[0]; o[13] = nTw[1]; o[14] = nTw[2]; o[15] = nTw[3];
         o[16] = tau; o[17] = conv; o[18] = mT; o[19] = mP;
         // reward on the new state
-        const float pr = 100.0f * (nC / 5.0f + conv);                    // :379
+        const float pr = 100.0f * (fdiv_c(nC, 5.0f) + conv);                    // :379
         const float sr = (mT + mP) / 2.0f;                               // :382
-        const float te = 1.0f - fabsf(nT - 373.15f) / 100.0f;            // :385
+        const float te = 1.0f - fdiv_c(fabsf(nT - 373.15f), 100.0f);            // :385
         const float pe = 1.0f - fabsf(nP - 3e5f) / 1e5f;                 // :386
         const float er = 50.0f * (te + pe);                              // :388
         const float cp = (-((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4]))) * 10.0f;   // :391
@@ -571,12 +571,12 @@ struct AdvancedPowerGrid {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sp[i] = emerg ? a[i] * 0.7f : a[i];                          // :248
-            const float pm = sp[i] / 100.0f, pe = s[20 + i] / 100.0f;    // :261-262
+            const float pm = fdiv_c(sp[i], 100.0f), pe = fdiv_c(s[20 + i], 100.0f);    // :261-262
             const float df = ((pm - pe) - D(i) * (s[16 + i] - 50.0f)) / (2.0f * H(i));   // :264-265
             nf[i] = s[16 + i] + dt * df;                                 // :272
             fsum = fsum + nf[i] * H(i);                                  // :276
         }
-        const float fsys = fsum / 17.0f;                                 // :275-276 (sum of inertias)
+        const float fsys = fdiv_c(fsum, 17.0f);                                 // :275-276 (sum of inertias)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                    // :279-289
             const float mr = ramp(i) * dt;
@@ -584,7 +584,7 @@ struct AdvancedPowerGrid {
             ch = fminf(fmaxf(ch, -mr), mr);
             nPg[i] = fminf(fmaxf(s[20 + i] + ch, Pmin(i)), Pmax(i));
         }
-        const float fdev = (fsys - 50.0f) / 50.0f;                       // :304
+        const float fdev = fdiv_c(fsys - 50.0f, 50.0f);                       // :304
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                    // :293-308
             float bl = base_load(i);
@@ -596,7 +596,7 @@ struct AdvancedPowerGrid {
         float nV[8], nTh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                                    // :368-389
-            const float inj = (i < 4) ? nPg[i] / 100.0f : (-nL[i - 4]) / 100.0f;
+            const float inj = (i < 4) ? fdiv_c(nPg[i], 100.0f) : fdiv_c(-nL[i - 4], 100.0f);
             float v = s[i] + 0.01f * inj;
             if (i == 0) v = a[4];
             if (i == 1) v = a[5];
@@ -606,7 +606,7 @@ struct AdvancedPowerGrid {
         float flow[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)                                      // :395-405
-            flow[i] = (((nV[i] * nV[i + 4]) / 0.1f) * det_sinf(nTh[i] - nTh[i + 4])) * 100.0f;
+            flow[i] = (fdiv_c(nV[i] * nV[i + 4], 0.1f) * det_sinf(nTh[i] - nTh[i + 4])) * 100.0f;
         float vmax = 0.0f, vmean = 0.0f, thmax = nTh[0], thmin = nTh[0], fmax_dev = 0.0f;
         bool vviol = false;
 #pragma unroll
@@ -619,7 +619,7 @@ struct AdvancedPowerGrid {
         vmean = vmean / 8.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) fmax_dev = fmaxf(fmax_dev, fabsf(nf[i] - 50.0f));
-        const float stab = fmaxf(fminf(fminf(1.0f - vmax, 1.0f - (thmax - thmin) / 3.14159265358979323846f),
+        const float stab = fmaxf(fminf(fminf(1.0f - vmax, 1.0f - fdiv_c(thmax - thmin, 3.14159265358979323846f)),
                                        1.0f - fmax_dev / 0.5f), 0.0f);  // :417-434
 #pragma unroll
         for (int i = 0; i < 8; ++i) { o[i] = nV[i]; o[8 + i] = nTh[i]; }
@@ -627,10 +627,10 @@ struct AdvancedPowerGrid {
         for (int i = 0; i < 4; ++i) { o[16 + i] = nf[i]; o[20 + i] = nPg[i]; o[24 + i] = nL[i]; o[28 + i] = flow[i]; }
         // reward :436-482
         const float ferr = fabsf(fsys - 50.0f);
-        const float r_f = 100.0f * det_expf((-ferr) / 0.1f);
-        const float r_v = 50.0f * det_expf((-vmean) / 0.05f);
+        const float r_f = 100.0f * det_expf(fdiv_c(-ferr, 0.1f));
+        const float r_v = 50.0f * det_expf(fdiv_c(-vmean, 0.05f));
         const float tg = ((nPg[0] + nPg[1]) + nPg[2]) + nPg[3], tl = ((nL[0] + nL[1]) + nL[2]) + nL[3];
-        const float r_b = 30.0f * det_expf((-fabsf(tg - tl)) / 10.0f);
+        const float r_b = 30.0f * det_expf(fdiv_c(-fabsf(tg - tl), 10.0f));
         const float r_e = -(0.01f * ((((nPg[0] * nPg[0]) + (nPg[1] * nPg[1])) + (nPg[2] * nPg[2])) + (nPg[3] * nPg[3])));
         const float r_c = (-(((((fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2])) + fabsf(a[3])) + fabsf(a[4])) + fabsf(a[5]))) * 1.0f;
         out.reward = (((((r_f + r_v) + r_b) + r_e) + r_c) + (-a[6]) * 50.0f) + (-a[7]) * 200.0f;

@@ -41,20 +41,12 @@ struct StepArgs {
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
 };
 
-// IndustrialEnv.step for one lane, entirely in registers (base.py:157-213).
+// IndustrialEnv.step for one lane, entirely in registers (base.py:157-213), in two halves so that
+// the paired rollout kernel can run them in different waves: pre_core = everything that feeds the
+// next state, post_core = reward / penalties / termination on the finished transition.
 template <class Env>
-__device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[Env::A],
-                                          const double (&nz)[Env::KS > 0 ? Env::KS : 1], int step_pre,
-                                          int max_steps, float dt32, double dt, uint32_t cmask,
-                                          float (&n)[Env::S], StepResult<Env> &out)
+__device__ __forceinline__ void clip_action(float (&a)[Env::A])
 {
-    using R = typename Env::reward_t;
-    if constexpr (Env::CUSTOM_STEP) {             // the Advanced envs override step() wholesale
-        Env::custom_step(s, a, step_pre, max_steps, dt32, n, out);
-        out.viol_bits &= cmask;
-        out.nviol = __popc(out.viol_bits);
-        return;
-    } else {
 #pragma unroll
     for (int k = 0; k < Env::A; ++k) {            // base.py:167 np.clip(action, -1, 1) == min(max(x,lo),hi)
         float x = a[k];
@@ -62,8 +54,13 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
         x = (x > 1.0f) ? 1.0f : x;
         a[k] = x;
     }
-    const uint32_t vb = Env::violated(s, a) & cmask;   // base.py:170 (and again :180, same inputs); cmask: base.py:224-228
-    Env::dynamics(s, a, nz, dt32, dt, n);         // base.py:173
+}
+
+template <class Env>
+__device__ __forceinline__ void post_core(const float (&n)[Env::S], const float (&a)[Env::A], uint32_t vb,
+                                          int step_pre, int max_steps, StepResult<Env> &out)
+{
+    using R = typename Env::reward_t;
     R r = Env::reward(n, a);                      // base.py:176
 #pragma unroll
     for (int k = 0; k < 3; ++k)                   // base.py:179-183, constraint order
@@ -75,6 +72,24 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
     if (ncrit > 0) { term = true; r = r - (R)1000; }  // base.py:195-198
     out.reward = r; out.viol_bits = vb; out.nviol = nviol; out.ncrit = ncrit;
     out.terminated = term; out.truncated = trunc; out.shutdown = ncrit > 0;   // info['critical_shutdown'], base.py:210
+}
+
+template <class Env>
+__device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[Env::A],
+                                          const double (&nz)[Env::KS > 0 ? Env::KS : 1], int step_pre,
+                                          int max_steps, float dt32, double dt, uint32_t cmask,
+                                          float (&n)[Env::S], StepResult<Env> &out)
+{
+    if constexpr (Env::CUSTOM_STEP) {             // the Advanced envs override step() wholesale
+        Env::custom_step(s, a, step_pre, max_steps, dt32, n, out);
+        out.viol_bits &= cmask;
+        out.nviol = __popc(out.viol_bits);
+        return;
+    } else {
+        clip_action<Env>(a);
+        const uint32_t vb = Env::violated(s, a) & cmask;   // base.py:170 (and again :180, same inputs); cmask: base.py:224-228
+        Env::dynamics(s, a, nz, dt32, dt, n);         // base.py:173
+        post_core<Env>(n, a, vb, step_pre, max_steps, out);
     }
 }
 

@@ -12,7 +12,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'rollout_kernel' in r['Kernel_Name'] or 'step_kernel' in r['Kernel_Name']:
+    if any(x in r['Kernel_Name'] for x in ('rollout_kernel', 'rollout_pair', 'step_kernel')):
         acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)

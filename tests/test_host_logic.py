@@ -172,3 +172,19 @@ def test_behaviour_policy_tables():
     assert float(p.p_uniform) == np.float32(0.3) and np.allclose(p.half_range, [0, 0, 0, .5, .5, .5, .5])
     with pytest.raises(AssertionError):
         ni.random_agent(4, 2, -1.0, 2.0)
+
+
+def test_constant_division_is_correctly_rounded(tmp_path):
+    """Every divisor the device code hands to fdiv_c (csrc/nig_envs.hpp) is proven exhaustively: the
+    4-instruction sequence equals IEEE x / c for all 2^23 significands (tests/constdiv_check.c)."""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "neorl-industrial-gym_amd", "csrc", "nig_envs.hpp")).read()
+    consts = sorted({m.group(1) for m in re.finditer(r"fdiv_c\([^;]*?,\s*([0-9.eE+-]+)f\)", src)})
+    assert len(consts) >= 10, consts
+    exe = tmp_path / "constdiv_check"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "constdiv_check.c"), "-lm"], check=True)
+    out = subprocess.run([str(exe)] + consts, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert out.stdout.count("mismatches=0") == len(consts), out.stdout
