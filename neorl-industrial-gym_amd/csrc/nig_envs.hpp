@@ -33,6 +33,7 @@ struct ChemicalReactor {
     static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
     static constexpr int STEP_WAVES = 7;          // waves per SIMD the step kernel is compiled for (no spills at this cap)
+    static constexpr int ROLLOUT_WAVES = 4;       // same, for the fused rollout kernels
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -60,12 +61,28 @@ struct ChemicalReactor {
         n[4] = 0.0 + 0.1 * (double)z[4];      n[5] = 0.0 + 2.0 * (double)z[5];
         n[6] = 0.0 + 1.0 * (double)z[6];      n[7] = 0.0 + 5.0 * (double)z[7];
     }
+    // Two draws per step: launch counters 2k-1 and 2k share ONE Philox block (counter word t = k, words
+    // 0-1 for the odd step, 2-3 for the even one; a fresh env's first step is t = 1) -- the 20
+    // quarter-rate multiplies of a block were a fifth of this env's step, and half of every block used
+    // to be thrown away.
+    static constexpr bool SHARED_STEP_BLOCK = true;
+    __device__ static u32x4 step_block(const RngKey &k)            // the block of the pair that holds counter k.t
+    {
+        RngKey kk = k;
+        kk.t = (k.t + 1u) >> 1;
+        return kk.block(STREAM_STEP);
+    }
+    __device__ static void step_noise(uint32_t w0, uint32_t w1, const float4 *tab, double (&n)[KS])
+    {
+        const float z0 = probit_normal(w0, tab), z1 = probit_normal(w1, tab);
+        n[0] = 0.0 + 0.1 * (double)z0;        // temp_noise_std / 10, :149
+        n[1] = 0.0 + 500.0 * (double)z1;      // pressure_noise_std / 10, :159
+    }
     __device__ static void draw_step(const RngKey &k, double (&n)[KS])
     {
-        float z[KS];
-        gen_normals<KS>(k, STREAM_STEP, z);
-        n[0] = 0.0 + 0.1 * (double)z[0];      // temp_noise_std / 10, :149
-        n[1] = 0.0 + 500.0 * (double)z[1];    // pressure_noise_std / 10, :159
+        const u32x4 x = step_block(k);
+        const bool second = (k.t & 1u) == 0;
+        step_noise(second ? x.z : x.x, second ? x.w : x.y, k.tab, n);
     }
 
     // constraint checks on the PRE-state, :292-305; bit k set = violated
@@ -141,8 +158,10 @@ struct ChemicalReactor {
 struct PowerGrid {
     static constexpr int ID = 1, S = 32, A = 8, KS = 23, KR = 31, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~18 % of lanes finish per step (episodes of ~6 steps)
+    static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     static constexpr int STEP_WAVES = 2;          // 23 fp64 noise values + 2x32 state registers: ~184 VGPRs
+    static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -279,8 +298,10 @@ struct PowerGrid {
 struct RobotAssembly {
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
+    static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     static constexpr int STEP_WAVES = 5;
+    static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels
     using reward_t = double;
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -435,7 +456,9 @@ struct StepResult {
 struct AdvancedChemicalReactor {
     static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr int STEP_WAVES = 5;
+    static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels
     using reward_t = float;    // float(total_reward) of a float32 scalar, :404
     static constexpr uint32_t CRIT_MASK = 0u;
     __device__ static constexpr float penalty(int) { return 0.0f; }
@@ -531,7 +554,9 @@ struct AdvancedChemicalReactor {
 struct AdvancedPowerGrid {
     static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
+    static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr int STEP_WAVES = 5;
+    static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     using reward_t = float;
     static constexpr uint32_t CRIT_MASK = 0u;
     __device__ static constexpr float penalty(int) { return 0.0f; }

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 
 #include "../../include/nig.h"
 #include "nig_envs.hpp"
@@ -23,6 +24,25 @@
 namespace nig {
 
 constexpr int BLOCK = 256;
+
+// One 16-byte store per call.  A HIP float4 assignment is scalarised and re-merged by hipcc, which can
+// pick 12+16+16+4-byte pieces for a 48-byte row (misaligned dwordx4: -20 % on the row-major
+// trajectory); a native vector store stays one aligned global_store_dwordx4.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(float *dst16, float a, float b, float c, float d)
+{
+    v4f v = {a, b, c, d};
+    *reinterpret_cast<v4f *>(dst16) = v;
+}
+// Per-step rollout outputs are written once and read by nobody on the device: streaming (nt) stores
+// keep them from evicting the action ring and the generator table from L2 (+5..16 % on the fused
+// rollout).  Only for stores that cover whole lines per instruction -- nt on the lane-strided 16-byte
+// pieces of an untransposed row-major row HALVED the 1M-lane rate (no write-combining in L2).
+template <class T>
+__device__ __forceinline__ void stream_store(T *dst, T v)
+{
+    __builtin_nontemporal_store(v, dst);
+}
 constexpr int REDUCE_BLOCKS = 256;
 constexpr int64_t POLICY_BYTES = 2048;     // device copy of nig_policy at the workspace tail
 
@@ -41,9 +61,9 @@ struct StepArgs {
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
 };
 
-// IndustrialEnv.step for one lane, entirely in registers (base.py:157-213), in two halves so that
-// the paired rollout kernel can run them in different waves: pre_core = everything that feeds the
-// next state, post_core = reward / penalties / termination on the finished transition.
+// IndustrialEnv.step for one lane, entirely in registers (base.py:157-213): action clip, constraint
+// check on the pre-state and dynamics, then post_core = reward / penalties / termination on the
+// finished transition.
 template <class Env>
 __device__ __forceinline__ void clip_action(float (&a)[Env::A])
 {
@@ -112,6 +132,25 @@ __device__ __forceinline__ RngKey make_key(uint64_t gi, uint32_t t, uint32_t see
     k.env_lo = (uint32_t)gi; k.env_hi = (uint32_t)(gi >> 32);
     k.t = t; k.seed_lo = seed_lo; k.seed_hi = seed_hi; k.tab = tab;
     return k;
+}
+
+// Env hooks that only some envs have, callable from generic lambdas (where a discarded
+// `if constexpr` branch is still name-checked because Env is not the lambda's own parameter).
+template <class Env>
+__device__ __forceinline__ u32x4 pair_block(const RngKey &k)
+{
+    if constexpr (Env::SHARED_STEP_BLOCK) return Env::step_block(k);
+    else return u32x4{0u, 0u, 0u, 0u};
+}
+template <class Env>
+__device__ __forceinline__ void pair_noise(uint32_t w0, uint32_t w1, const float4 *tab, double (&n)[Env::KS > 0 ? Env::KS : 1])
+{
+    if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise(w0, w1, tab, n);
+}
+template <class Env>
+__device__ __forceinline__ void draw_one(const RngKey &k, double (&n)[Env::KS > 0 ? Env::KS : 1])
+{
+    if constexpr (Env::KS > 0) Env::draw_step(k, n);
 }
 
 // Stage the 12 KiB probit table (normal transform of the generator) in LDS.  Every thread of the block
@@ -343,7 +382,8 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
 // a pre-filled action ring.
 struct RolloutArgs {
     StepArgs s;                 // actions = ring base; reward/flags = per-step output bases (optional)
-    int n_steps;
+    int n_steps;                // steps [it0, n_steps) of the call are run by this launch
+    int it0;
     int ring_len; uint32_t slot_stride;          // elements between ring slots
     uint32_t out_stride;                         // elements between per-step reward/flag rows (0: overwrite)
     float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional trajectory, [n_steps][S][ld] ...
@@ -354,8 +394,8 @@ struct RolloutArgs {
 //      3 = + observation row-major [B][S].  Compile-time so that the number of stores per
 // iteration is static and the wait for the prefetched action is a counted vmcnt(N), not a
 // full drain of the iteration's stores.
-template <class Env, int OUT>
-__global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
+template <class Env, int OUT, bool PAIRED>
+__global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
@@ -370,14 +410,15 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     __shared__ float s_init[COMPACT ? S * BLOCK : 1];
     __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
     __shared__ int s_cnt[COMPACT ? NWAVE : 1];
+    __shared__ v4f s_tr[OUT == 3 ? NWAVE : 1][OUT == 3 ? 64 * (S / 4) : 1];   // per-wave transpose of the row-major observation rows
     NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
     const bool in_range = base + tid < p.B;
-    if constexpr (!COMPACT) {
-        if (!in_range) return;       // compacting blocks keep every thread for the barriers
-    }
+    if constexpr (!COMPACT && OUT != 3) {
+        if (!in_range) return;       // compacting blocks keep every thread for the barriers, row-major
+    }                                // output keeps them to move the rows of a partial wave's live lanes
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
     const uint64_t gi = p.env0 + (uint64_t)(base + tid);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
@@ -395,37 +436,31 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
     // wait for a prefetched action also waits for every store issued before it; at distance 2 those
     // are the stores of two steps ago, acknowledged long before (a distance-1 prefetch stalled ~20 %
     // of the wave's cycles on the previous step's store acknowledgements).
+    //
+    // PAIRED (envs that share one Philox block between the two steps of a pair of launch counters
+    // 2k-1, 2k: ChemicalReactor; the launch must start on an odd counter, the host peels a misaligned
+    // first step into a launch of the unpaired form): process noise is produced one step AHEAD, in the
+    // shadow of the current step's stores -- the tail of a pair's second step runs the Philox rounds of
+    // the next pair and the normal transform of its first step, the tail of the first step transforms
+    // the two words kept for the second.  One block per two steps, LDS table latency off the critical
+    // path.
+    constexpr bool SHARE = PAIRED;
+    static_assert(!PAIRED || (Env::SHARED_STEP_BLOCK && KS > 0 && KS <= 2), "a shared step block holds two steps");
     const float *ring = p.actions + base;
     float bufA[A], bufB[A];
-    int slot = (q.ring_len > 1) ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < A; ++k) bufA[k] = in_range ? (ring + k * p.ld_act)[tid] : 0.0f;
-    {
-        const float *nx = ring + (size_t)slot * q.slot_stride;
-#pragma unroll
-        for (int k = 0; k < A; ++k) bufB[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
-    }
-    // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
-    // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
-    // waits sized for the first one.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    // Process noise is produced one step AHEAD (ping-pong sets nzA/nzB like the action buffers): the
-    // Philox rounds and the LDS table reads of step it+1 are issued in the shadow of step it's stores
-    // instead of sitting, un-overlapped, at the head of the step that consumes them.
-    // (only for envs with a few draws per step: two sets of PowerGrid's 23 fp64 values would cost 92 VGPRs)
-    constexpr bool LOOKAHEAD = (KS > 0 && KS <= 4);
     double nzA[KSN], nzB[KSN];
-    if constexpr (LOOKAHEAD) Env::draw_step(make_key(gi, t_base + 1u, p.seed_lo, p.seed_hi, s_probit), nzA);
-    else { nzA[0] = 0.0; nzB[0] = 0.0; }
+    nzA[0] = 0.0; nzB[0] = 0.0;
+    uint32_t kept0 = 0u, kept1 = 0u;          // words 2-3 of the current pair's block
+    int slot = 0;
 
-    auto one_step = [&](float (&abuf)[A], double (&nz)[KSN], double (&nz_next)[KSN], const int it) __attribute__((always_inline)) {
+    using unpaired = std::integral_constant<int, 0>;
+    auto one_step = [&](auto pos_tag, float (&abuf)[A], double (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const uint32_t orow = (uint32_t)it * q.out_stride;
         const bool frozen = (ctr & NIG_CTR_DONE) != 0;             // no auto-reset: base.py:159-160
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
-        if constexpr (KS > 0 && !LOOKAHEAD) Env::draw_step(key, nz);
+        if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
@@ -446,36 +481,62 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
                 else ret = ret + (double)res.reward;
             }
         }
+        if constexpr (OUT == 3) {                  // stage this lane's row; read back transposed below
+            v4f *tr = s_tr[tid >> 6] + (tid & 63u) * (S / 4);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
+        }
         // Refill this buffer with the action of step it+2, issued BEFORE this step's stores: the
         // registers of `a` are dead by now (the load lands in place, no rotation of register sets),
         // and the in-order vmcnt wait at the top of step it+2 then only needs the stores of step
         // it-1 and older to have been acknowledged -- two full steps of slack.
-        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
         {
+            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
             const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
             for (int k = 0; k < A; ++k) abuf[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
         }
-        if constexpr (LOOKAHEAD) {                 // next step's noise (keyed by t+1), see above
-            Env::draw_step(make_key(gi, t_base + (uint32_t)it + 2u, p.seed_lo, p.seed_hi, s_probit), nz_next);
+        if constexpr (decltype(pos_tag)::value == 2) {         // next pair (counters t+1, t+2): block + first step's noise
+            const u32x4 x = pair_block<Env>(make_key(gi, t_base + (uint32_t)it + 2u, p.seed_lo, p.seed_hi, s_probit));
+            pair_noise<Env>(x.x, x.y, s_probit, nzA);
+            kept0 = x.z; kept1 = x.w;
             __builtin_amdgcn_sched_barrier(0);     // keep it here: hipcc would sink it back to its consumer
+        } else if constexpr (decltype(pos_tag)::value == 1) {  // this pair's second step
+            pair_noise<Env>(kept0, kept1, s_probit, nzB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (OUT == 3) {
+            // row-major transitions [step][lane][S] (the D4RL "observations[N,S]" layout).  A lane's row is
+            // 4*S contiguous bytes, but written lane by lane every store instruction would scatter 64
+            // 16-byte pieces at a 4*S-byte stride (partial lines: -15 % against the [S][lane] layout, -45 %
+            // with streaming stores).  The wave's 64 rows are one contiguous 256*S-byte block, so they go
+            // through a wave-private LDS image and leave in lane-contiguous order: S/4 stores of one
+            // contiguous KiB each.  (DS operations of one wave execute in order: the reads see the writes
+            // issued above without a wait in between.)
+            const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
+            const v4f *tr = s_tr[tid >> 6];
+            v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)it * q.obs_step_stride + (size_t)wave_env0 * S);
+            v4f v[S / 4];
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) v[k] = tr[lane + 64u * k];
+            if (wave_env0 + 64u <= p.B) {          // wave-uniform: the whole wave exists
+#pragma unroll
+                for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, v[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < S / 4; ++k)
+                    if (wave_env0 + (lane + 64u * k) / (unsigned)(S / 4) < p.B) stream_store(oo + lane + 64u * k, v[k]);
+            }
         }
         if (in_range) {
-        if constexpr (OUT == 3) {
-            // row-major transitions [step][lane][S] (the D4RL "observations[N,S]" layout): each lane
-            // owns 4*S contiguous bytes, written as S/4 16-byte stores (12 dword stores -> 3 for CR)
-            float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) +
-                         (size_t)(base + tid) * (S / 4);
-#pragma unroll
-            for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]);
-        } else if constexpr (OUT == 2) {
+        if constexpr (OUT == 2) {
             float *oo = q.obs_out + (size_t)it * q.obs_step_stride + base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) (oo + k * q.ld_obs_out)[tid] = n[k];
+            for (int k = 0; k < S; ++k) stream_store(oo + k * q.ld_obs_out + tid, n[k]);
         }
         if constexpr (OUT >= 1) {
-            (p.reward + base + orow)[tid] = rew;
-            (p.flags + base + orow)[tid] = fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u);
+            stream_store(p.reward + base + orow + tid, rew);
+            stream_store(p.flags + base + orow + tid, fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u));
         }
         }   // in_range
         if (done) {
@@ -525,14 +586,34 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(const RolloutArgs q)
         for (int k = 0; k < S; ++k) s[k] = n[k];
     };
 
+    int it = q.it0;
+    slot = it % q.ring_len;
+    if constexpr (SHARE) {
+        const u32x4 x = pair_block<Env>(make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit));
+        pair_noise<Env>(x.x, x.y, s_probit, nzA);
+        kept0 = x.z; kept1 = x.w;
+    }
+    {
+        const float *nx = ring + (size_t)slot * q.slot_stride;        // step `it`
+#pragma unroll
+        for (int k = 0; k < A; ++k) bufA[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
+        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+        nx = ring + (size_t)slot * q.slot_stride;                     // step `it + 1`
+#pragma unroll
+        for (int k = 0; k < A; ++k) bufB[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
+    }
+    // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
+    // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
+    // waits sized for the first one.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
     // no conditional inside the loop: a phi on the action registers would put register copies (and
     // with them the wait for the freshest loads) on the back edge
-    int it = 0;
     for (; it + 1 < q.n_steps; it += 2) {
-        one_step(bufA, nzA, nzB, it);
-        one_step(bufB, nzB, nzA, it + 1);
+        one_step(std::integral_constant<int, SHARE ? 1 : 0>{}, bufA, nzA, it);
+        one_step(std::integral_constant<int, SHARE ? 2 : 0>{}, bufB, nzB, it + 1);
     }
-    if (it < q.n_steps) one_step(bufA, nzA, nzB, it);
+    if (it < q.n_steps) one_step(unpaired{}, bufA, nzA, it);
     if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
@@ -663,9 +744,9 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         policy_action<Env>(q.pol, s, key, integ, eprev, a);
         if (q.obs_out) {
-            float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) + (size_t)(base + tid) * (S / 4);
+            float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + tid) * S;
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+            for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
         }
         if (q.act_out) {
             float *ao = q.act_out + (size_t)it * q.act_step_stride + base;
@@ -845,9 +926,9 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
         const bool frozen = (ctr & NIG_CTR_DONE) != 0;
         if (writer && !frozen) {
             if (q.obs_out) {
-                float4 *oo = reinterpret_cast<float4 *>(q.obs_out + (size_t)it * q.obs_step_stride) + (size_t)li * (S / 4);
+                float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)li * S;
 #pragma unroll
-                for (int k = 0; k < S / 4; ++k) oo[k] = make_float4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+                for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
             }
             if (q.act_out) {
                 float *ao = q.act_out + (size_t)it * q.act_step_stride;
@@ -1123,20 +1204,38 @@ static void launch_step(const StepArgs &a, bool parity, hipStream_t st)
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
 }
 
-template <class Env>
-static void launch_rollout_env(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
+template <class Env, bool PAIRED>
+static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
     switch (out_mode) {
-    case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    case 2: hipLaunchKernelGGL((rollout_kernel<Env, 2>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    default: hipLaunchKernelGGL((rollout_kernel<Env, 3>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 2: hipLaunchKernelGGL((rollout_kernel<Env, 2, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    default: hipLaunchKernelGGL((rollout_kernel<Env, 3, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
     }
 }
 
-static void launch_rollout(int env, int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
+// t0 = launch counter of the call's first step (host-known: rollouts are never graph-captured)
+template <class Env>
+static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, unsigned grid, hipStream_t st)
 {
-    NIG_DISPATCH_ENV(env, launch_rollout_env<E>(out_mode, q, grid, st));
+    if constexpr (Env::SHARED_STEP_BLOCK) {
+        RolloutArgs r = q;
+        if ((t0 & 1u) == 0u) {                    // starts on the second step of a pair: peel it
+            r.n_steps = 1;
+            launch_rollout_form<Env, false>(out_mode, r, grid, st);
+            if (q.n_steps == 1) return;
+            r.n_steps = q.n_steps; r.it0 = 1;
+        }
+        launch_rollout_form<Env, true>(out_mode, r, grid, st);
+    } else {
+        launch_rollout_form<Env, false>(out_mode, q, grid, st);
+    }
+}
+
+static void launch_rollout(int env, int out_mode, const RolloutArgs &q, uint32_t t0, unsigned grid, hipStream_t st)
+{
+    NIG_DISPATCH_ENV(env, launch_rollout_env<E>(out_mode, q, t0, grid, st));
 }
 
 static StepArgs base_step_args(const nig_handle *h)
@@ -1387,7 +1486,7 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
     q.s.actions = action_ring; q.s.ld_act = (uint32_t)ld_act;
     q.s.reward = reward_out; q.s.flags = flags_out;
     q.s.t_ptr = nullptr; q.s.t_off = h->t;
-    q.n_steps = n_steps; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
+    q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
     q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = obs_aos ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if ((reward_out == nullptr) != (flags_out == nullptr))
@@ -1395,7 +1494,7 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
     if (obs_out && !reward_out)
         return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
     const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
-    launch_rollout(h->env, out_mode, q, grid_for(h->B), st);
+    launch_rollout(h->env, out_mode, q, h->t + 1u, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;

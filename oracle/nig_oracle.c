@@ -807,9 +807,12 @@ void oracle_gen_step_noise(int env, uint64_t seed, uint64_t env_index, uint32_t 
 {
     float z[24];
     if (env == ORACLE_CR) {                                    /* chemical_reactor.py:149,159 */
-        gen_normals(seed, env_index, t, STREAM_STEP, 2, z);
-        noise[0] = 0.0 + 0.1 * (double)z[0];
-        noise[1] = 0.0 + 500.0 * (double)z[1];
+        /* two draws per step: launch counters 2k-1 and 2k share one Philox block (counter word k),
+         * words 0-1 for the odd counter, 2-3 for the even one */
+        gen_normals(seed, env_index, (t + 1u) >> 1, STREAM_STEP, 4, z);
+        const float *zz = z + 2 * (1u - (t & 1u));
+        noise[0] = 0.0 + 0.1 * (double)zz[0];
+        noise[1] = 0.0 + 500.0 * (double)zz[1];
     } else if (env == ORACLE_PG) {                             /* power_grid.py:136,140,144 */
         gen_normals(seed, env_index, t, STREAM_STEP, 23, z);
         for (int i = 0; i < 8; i++) noise[i] = 0.0 + 0.005 * (double)z[i];
