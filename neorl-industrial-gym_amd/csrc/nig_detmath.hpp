@@ -221,17 +221,31 @@ __device__ const float4 NIG_PROBIT[768] = {
 #include "nig_probit_table.inc"
 };
 
+// In two halves so a kernel can put other work between the LDS read and its use.
+struct ProbitFetch { float4 c; float t; uint32_t v; };
+
+__device__ __forceinline__ ProbitFetch probit_fetch(uint32_t word, const float4 *tab)
+{
+    ProbitFetch f;
+    f.v = word >> 8;
+    const float x = (float)(f.v & 0x7FFFFFu) + 0.5f;         // exact
+    const uint32_t b = f32_bits(x);
+    f.c = tab[(b >> 18) - (126u << 5)];
+    f.t = (float)(b & 0x3FFFFu) * (1.0f / 262144.0f);        // exact
+    return f;
+}
+
+__device__ __forceinline__ float probit_eval(const ProbitFetch &f)
+{
+    float z = f.c.w * f.t + f.c.z;
+    z = z * f.t + f.c.y;
+    z = z * f.t + f.c.x;
+    return (f.v & 0x800000u) ? -z : z;
+}
+
 __device__ __forceinline__ float probit_normal(uint32_t word, const float4 *tab)
 {
-    const uint32_t v = word >> 8;
-    const float f = (float)(v & 0x7FFFFFu) + 0.5f;           // exact
-    const uint32_t b = f32_bits(f);
-    const float4 c = tab[(b >> 18) - (126u << 5)];
-    const float t = (float)(b & 0x3FFFFu) * (1.0f / 262144.0f);   // exact
-    float z = c.w * t + c.z;
-    z = z * t + c.y;
-    z = z * t + c.x;
-    return (v & 0x800000u) ? -z : z;
+    return probit_eval(probit_fetch(word, tab));
 }
 
 __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // exact in float32

@@ -72,11 +72,20 @@ struct ChemicalReactor {
         kk.t = (k.t + 1u) >> 1;
         return kk.block(STREAM_STEP);
     }
+    __device__ static void step_noise_fetch(uint32_t w0, uint32_t w1, const float4 *tab, ProbitFetch (&f)[KS])
+    {
+        f[0] = probit_fetch(w0, tab); f[1] = probit_fetch(w1, tab);
+    }
+    __device__ static void step_noise_eval(const ProbitFetch (&f)[KS], double (&n)[KS])
+    {
+        n[0] = 0.0 + 0.1 * (double)probit_eval(f[0]);        // temp_noise_std / 10, :149
+        n[1] = 0.0 + 500.0 * (double)probit_eval(f[1]);      // pressure_noise_std / 10, :159
+    }
     __device__ static void step_noise(uint32_t w0, uint32_t w1, const float4 *tab, double (&n)[KS])
     {
-        const float z0 = probit_normal(w0, tab), z1 = probit_normal(w1, tab);
-        n[0] = 0.0 + 0.1 * (double)z0;        // temp_noise_std / 10, :149
-        n[1] = 0.0 + 500.0 * (double)z1;      // pressure_noise_std / 10, :159
+        ProbitFetch f[KS];
+        step_noise_fetch(w0, w1, tab, f);
+        step_noise_eval(f, n);
     }
     __device__ static void draw_step(const RngKey &k, double (&n)[KS])
     {

@@ -148,6 +148,16 @@ __device__ __forceinline__ void pair_noise(uint32_t w0, uint32_t w1, const float
     if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise(w0, w1, tab, n);
 }
 template <class Env>
+__device__ __forceinline__ void pair_fetch(uint32_t w0, uint32_t w1, const float4 *tab, ProbitFetch (&f)[Env::KS > 0 ? Env::KS : 1])
+{
+    if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise_fetch(w0, w1, tab, f);
+}
+template <class Env>
+__device__ __forceinline__ void pair_eval(const ProbitFetch (&f)[Env::KS > 0 ? Env::KS : 1], double (&n)[Env::KS > 0 ? Env::KS : 1])
+{
+    if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise_eval(f, n);
+}
+template <class Env>
 __device__ __forceinline__ void draw_one(const RngKey &k, double (&n)[Env::KS > 0 ? Env::KS : 1])
 {
     if constexpr (Env::KS > 0) Env::draw_step(k, n);
@@ -452,13 +462,21 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     nzA[0] = 0.0; nzB[0] = 0.0;
     uint32_t kept0 = 0u, kept1 = 0u;          // words 2-3 of the current pair's block
     int slot = 0;
+    // Wave-uniform running pointers instead of it * stride products: the per-step 64-bit scalar
+    // multiplies and adds of the address arithmetic were ~40 of the step's ~80 SALU issue slots.
+    const float *act_next = ring;              // ring slot of the step whose action is fetched next
+    float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
+    uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
+    float *obs_row = nullptr;                  // this step's observation block / rows
+    if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S;
+    if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
+    const bool may_freeze = !autoreset || base + BLOCK > p.B;   // block-uniform: lanes can be frozen (finished, or out of range)
 
     using unpaired = std::integral_constant<int, 0>;
     auto one_step = [&](auto pos_tag, float (&abuf)[A], double (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
-        const uint32_t orow = (uint32_t)it * q.out_stride;
-        const bool frozen = (ctr & NIG_CTR_DONE) != 0;             // no auto-reset: base.py:159-160
+        const bool frozen = may_freeze && (ctr & NIG_CTR_DONE) != 0;   // no auto-reset: base.py:159-160
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
@@ -469,17 +487,34 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         const bool done = (res.terminated || res.truncated) && !frozen;
         uint32_t fl = pack_flags<Env>(res, step);
         float rew = (float)res.reward;
-        if (frozen) {                              // untouched lane: discard the speculative step
-            fl = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
-            rew = 0.0f;
+        if (may_freeze) {                          // skipped wholesale (scalar branch) when no lane can be frozen
+            if (frozen) {                          // untouched lane: discard the speculative step
+                fl = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+                rew = 0.0f;
 #pragma unroll
-            for (int k = 0; k < S; ++k) n[k] = s[k];
-        } else {
+                for (int k = 0; k < S; ++k) n[k] = s[k];
+            }
+        }
+        if (!frozen) {
             ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
             if (tally) {
                 if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
                 else ret = ret + (double)res.reward;
             }
+        }
+        // Next step's process noise, first half: (second step of a pair) the Philox rounds of the next
+        // pair, then the index arithmetic and the LDS table reads of the two draws.  The cubic that
+        // consumes them runs after this step's stores: the reads' latency is covered by the store traffic
+        // instead of a wait.
+        ProbitFetch pf[KSN];
+        if constexpr (decltype(pos_tag)::value == 2) {         // next pair: counters t+1, t+2
+            const u32x4 x = pair_block<Env>(make_key(gi, t_base + (uint32_t)it + 2u, p.seed_lo, p.seed_hi, s_probit));
+            pair_fetch<Env>(x.x, x.y, s_probit, pf);
+            kept0 = x.z; kept1 = x.w;
+            __builtin_amdgcn_sched_barrier(0);     // keep it here: hipcc would sink it back to its consumer
+        } else if constexpr (decltype(pos_tag)::value == 1) {  // this pair's second step
+            pair_fetch<Env>(kept0, kept1, s_probit, pf);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (OUT == 3) {                  // stage this lane's row; read back transposed below
             v4f *tr = s_tr[tid >> 6] + (tid & 63u) * (S / 4);
@@ -491,19 +526,10 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         // and the in-order vmcnt wait at the top of step it+2 then only needs the stores of step
         // it-1 and older to have been acknowledged -- two full steps of slack.
         {
-            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-            const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
-            for (int k = 0; k < A; ++k) abuf[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
-        }
-        if constexpr (decltype(pos_tag)::value == 2) {         // next pair (counters t+1, t+2): block + first step's noise
-            const u32x4 x = pair_block<Env>(make_key(gi, t_base + (uint32_t)it + 2u, p.seed_lo, p.seed_hi, s_probit));
-            pair_noise<Env>(x.x, x.y, s_probit, nzA);
-            kept0 = x.z; kept1 = x.w;
-            __builtin_amdgcn_sched_barrier(0);     // keep it here: hipcc would sink it back to its consumer
-        } else if constexpr (decltype(pos_tag)::value == 1) {  // this pair's second step
-            pair_noise<Env>(kept0, kept1, s_probit, nzB);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < A; ++k) abuf[k] = in_range ? (act_next + k * p.ld_act)[tid] : 0.0f;
+            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+            act_next = (slot == 0) ? ring : act_next + q.slot_stride;
         }
         if constexpr (OUT == 3) {
             // row-major transitions [step][lane][S] (the D4RL "observations[N,S]" layout).  A lane's row is
@@ -515,7 +541,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             // issued above without a wait in between.)
             const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
             const v4f *tr = s_tr[tid >> 6];
-            v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)it * q.obs_step_stride + (size_t)wave_env0 * S);
+            v4f *oo = reinterpret_cast<v4f *>(obs_row);
             v4f v[S / 4];
 #pragma unroll
             for (int k = 0; k < S / 4; ++k) v[k] = tr[lane + 64u * k];
@@ -530,15 +556,23 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         }
         if (in_range) {
         if constexpr (OUT == 2) {
-            float *oo = q.obs_out + (size_t)it * q.obs_step_stride + base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) stream_store(oo + k * q.ld_obs_out + tid, n[k]);
+            for (int k = 0; k < S; ++k) stream_store(obs_row + k * q.ld_obs_out + tid, n[k]);
         }
         if constexpr (OUT >= 1) {
-            stream_store(p.reward + base + orow + tid, rew);
-            stream_store(p.flags + base + orow + tid, fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u));
+            stream_store(rew_row + tid, rew);
+            stream_store(fl_row + tid, fl | ((done && autoreset) ? NIG_FLAG_DID_RESET : 0u));
         }
         }   // in_range
+        if constexpr (OUT >= 1) { rew_row += q.out_stride; fl_row += q.out_stride; }
+        if constexpr (OUT >= 2) obs_row += q.obs_step_stride;
+        if constexpr (decltype(pos_tag)::value == 2) {         // second half: the normals themselves
+            __builtin_amdgcn_sched_barrier(0);
+            pair_eval<Env>(pf, nzA);
+        } else if constexpr (decltype(pos_tag)::value == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            pair_eval<Env>(pf, nzB);
+        }
         if (done) {
             lt.life += (long long)viol_ep;
             if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
@@ -601,6 +635,8 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         nx = ring + (size_t)slot * q.slot_stride;                     // step `it + 1`
 #pragma unroll
         for (int k = 0; k < A; ++k) bufB[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
+        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+        act_next = ring + (size_t)slot * q.slot_stride;               // step `it + 2`: the first refill
     }
     // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
     // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
