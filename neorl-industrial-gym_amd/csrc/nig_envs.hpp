@@ -33,7 +33,7 @@ struct ChemicalReactor {
     static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
     static constexpr int STEP_WAVES = 7;          // waves per SIMD the step kernel is compiled for (no spills at this cap)
-    static constexpr int ROLLOUT_WAVES = 4;       // same, for the fused rollout kernels
+    static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels (four action register sets in flight)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
     __device__ static constexpr float act_high(int) { return 1.0f; }

@@ -457,7 +457,12 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     constexpr bool SHARE = PAIRED;
     static_assert(!PAIRED || (Env::SHARED_STEP_BLOCK && KS > 0 && KS <= 2), "a shared step block holds two steps");
     const float *ring = p.actions + base;
-    float bufA[A], bufB[A];
+    // DEPTH = steps of slack between an action load and its use = ring of register sets = loop unroll.
+    // The wait for a prefetched action is in-order with the stores issued before it; at the headline
+    // size a step is ~1.2 us and a streaming store takes longer than two of them to be acknowledged.
+    // Four steps for the envs whose step is short enough that four copies stay inside the I-cache.
+    constexpr int DEPTH = PAIRED ? 4 : 2;
+    float buf[DEPTH][A];
     double nzA[KSN], nzB[KSN];
     nzA[0] = 0.0; nzB[0] = 0.0;
     uint32_t kept0 = 0u, kept1 = 0u;          // words 2-3 of the current pair's block
@@ -472,7 +477,6 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
     const bool may_freeze = !autoreset || base + BLOCK > p.B;   // block-uniform: lanes can be frozen (finished, or out of range)
 
-    using unpaired = std::integral_constant<int, 0>;
     auto one_step = [&](auto pos_tag, float (&abuf)[A], double (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
@@ -521,10 +525,10 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 #pragma unroll
             for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
         }
-        // Refill this buffer with the action of step it+2, issued BEFORE this step's stores: the
+        // Refill this buffer with the action of step it+DEPTH, issued BEFORE this step's stores: the
         // registers of `a` are dead by now (the load lands in place, no rotation of register sets),
-        // and the in-order vmcnt wait at the top of step it+2 then only needs the stores of step
-        // it-1 and older to have been acknowledged -- two full steps of slack.
+        // and the in-order vmcnt wait at the top of step it+DEPTH then only needs the stores of step
+        // it-1 and older to have been acknowledged -- DEPTH full steps of slack.
         {
 #pragma unroll
             for (int k = 0; k < A; ++k) abuf[k] = in_range ? (act_next + k * p.ld_act)[tid] : 0.0f;
@@ -627,17 +631,14 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         pair_noise<Env>(x.x, x.y, s_probit, nzA);
         kept0 = x.z; kept1 = x.w;
     }
-    {
-        const float *nx = ring + (size_t)slot * q.slot_stride;        // step `it`
 #pragma unroll
-        for (int k = 0; k < A; ++k) bufA[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
-        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-        nx = ring + (size_t)slot * q.slot_stride;                     // step `it + 1`
+    for (int j = 0; j < DEPTH; ++j) {                                  // steps it .. it + DEPTH - 1
+        const float *nx = ring + (size_t)slot * q.slot_stride;
 #pragma unroll
-        for (int k = 0; k < A; ++k) bufB[k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
+        for (int k = 0; k < A; ++k) buf[j][k] = in_range ? (nx + k * p.ld_act)[tid] : 0.0f;
         slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-        act_next = ring + (size_t)slot * q.slot_stride;               // step `it + 2`: the first refill
     }
+    act_next = ring + (size_t)slot * q.slot_stride;                   // step it + DEPTH: the first refill
     // Drain the prologue loads HERE (vmcnt(0); expcnt/lgkmcnt untouched).  Otherwise hipcc's waitcnt
     // pass merges "prologue loads still in flight" into the loop header and every iteration inherits
     // waits sized for the first one.
@@ -645,11 +646,22 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 
     // no conditional inside the loop: a phi on the action registers would put register copies (and
     // with them the wait for the freshest loads) on the back edge
-    for (; it + 1 < q.n_steps; it += 2) {
-        one_step(std::integral_constant<int, SHARE ? 1 : 0>{}, bufA, nzA, it);
-        one_step(std::integral_constant<int, SHARE ? 2 : 0>{}, bufB, nzB, it + 1);
+    using first = std::integral_constant<int, SHARE ? 1 : 0>;      // position in the pair (0: unpaired env)
+    using second = std::integral_constant<int, SHARE ? 2 : 0>;
+    for (; it + DEPTH <= q.n_steps; it += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j += 2) {
+            one_step(first{}, buf[j], nzA, it + j);
+            one_step(second{}, buf[j + 1], nzB, it + j + 1);
+        }
     }
-    if (it < q.n_steps) one_step(unpaired{}, bufA, nzA, it);
+    // tail: at most DEPTH - 1 steps (noise drawn past the last step is simply not used)
+    static_assert(DEPTH == 2 || DEPTH == 4, "tail written out for these depths");
+    if (it < q.n_steps) one_step(first{}, buf[0], nzA, it);
+    if constexpr (DEPTH == 4) {
+        if (it + 1 < q.n_steps) one_step(second{}, buf[1], nzB, it + 1);
+        if (it + 2 < q.n_steps) one_step(first{}, buf[2], nzA, it + 2);
+    }
     if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
