@@ -7,6 +7,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- python3 bench.py --no-cpu-baseline --no-parity "$@" > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
-find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+[ "$f" -ef "$out/${tag}_kernel_stats.csv" ] || cp "$f" $out/${tag}_kernel_stats.csv
 cat $out/${tag}_kernel_stats.csv | head -20
 cat $out/bench.json
