@@ -16,8 +16,8 @@ from .core import DatasetQuality, SafetyConstraint, SafetyMetrics
 _lib.lib()   # fail loudly here if libnig.so is missing
 
 from .batched import BatchedIndustrialEnv, MixedBatchedEnv, StepInfo  # noqa: E402
-from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalReactorEnv, IndustrialEnv,  # noqa: E402
-                   PowerGridEnv, RobotAssemblyEnv)
+from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalReactorEnv, HVACControlEnv,  # noqa: E402
+                   IndustrialEnv, PowerGridEnv, RobotAssemblyEnv, SteelAnnealingEnv, SupplyChainEnv, WaterTreatmentEnv)
 from .policies import (DevicePolicy, MLPPolicy, behaviour_policy, constant_agent, mpc_agent,  # noqa: E402
                        pid_agent, random_agent)
 from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
@@ -25,7 +25,8 @@ from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
 __version__ = "0.1.0"
 __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
-    "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "AdvancedChemicalReactorEnv", "AdvancedPowerGridEnv", "BatchedIndustrialEnv", "MixedBatchedEnv", "StepInfo",
+    "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "AdvancedChemicalReactorEnv", "AdvancedPowerGridEnv",
+    "HVACControlEnv", "WaterTreatmentEnv", "SteelAnnealingEnv", "SupplyChainEnv", "BatchedIndustrialEnv", "MixedBatchedEnv", "StepInfo",
     "make", "make_batched", "evaluate_with_safety", "DevicePolicy", "MLPPolicy", "behaviour_policy", "constant_agent",
     "mpc_agent", "pid_agent", "random_agent",
 ]

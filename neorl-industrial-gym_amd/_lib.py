@@ -47,10 +47,10 @@ class Layout(C.Structure):
 
 class Policy(C.Structure):
     """nig_policy (include/nig.h, "nig-policy-v1")."""
-    _fields_ = [("kind", C.c_int32), ("colmask", C.c_uint32), ("Wt", (C.c_float * 8) * 32), ("b", C.c_float * 8),
-                ("sigma", C.c_float * 8), ("half_range", C.c_float * 8), ("p_uniform", C.c_float),
+    _fields_ = [("kind", C.c_int32), ("colmask", C.c_uint32), ("Wt", (C.c_float * 10) * 32), ("b", C.c_float * 10),
+                ("sigma", C.c_float * 10), ("half_range", C.c_float * 10), ("p_uniform", C.c_float),
                 ("uniform_range", C.c_float), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
-                ("kp", C.c_float), ("ki", C.c_float), ("kd", C.c_float), ("setpoint", C.c_float * 8)]
+                ("kp", C.c_float), ("ki", C.c_float), ("kd", C.c_float), ("setpoint", C.c_float * 10)]
 
 
 POLICY_AFFINE, POLICY_PID = 1, 2

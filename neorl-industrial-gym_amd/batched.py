@@ -17,7 +17,9 @@ from .core import SafetyMetrics, make_box
 
 ENV_IDS = {"ChemicalReactor-v0": 0, "PowerGrid-v0": 1, "RobotAssembly-v0": 2,
            # candidate rows: registered upstream (utils.py:30-31) but not instantiable there
-           "AdvancedChemicalReactor-v0": 3, "AdvancedPowerGrid-v0": 4}
+           "AdvancedChemicalReactor-v0": 3, "AdvancedPowerGrid-v0": 4,
+           # README-only upstream (README.md:28-32): build-specified plants, spec_plants.py
+           "HVACControl-v0": 5, "WaterTreatment-v0": 6, "SteelAnnealing-v0": 7, "SupplyChain-v0": 8}
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -439,6 +439,155 @@ struct RobotAssembly {
 };
 
 
+// =================================================================================
+// HVACControl-v0 / WaterTreatment-v0 / SteelAnnealing-v0 / SupplyChain-v0 -- BUILD-SPECIFIED.
+//
+// The reference's README lists these four (name, dims, constraint names: README.md:28-32) and ships
+// no implementation, so there is no reference output and parity is undefined; they complete the
+// "all 7 envs" mixed batch of BASELINE.json.  One plant family (first-order relaxation + linear
+// coupling + linear actuator gains, velocity-form actuators, box constraints), four tables:
+// spec_plants.py is the source of the numbers and of the model's description; the table below is
+// generated from it (nig_spec_plants.inc; the oracle compiles the same data with its own code).
+// They go through the base step template like the three real envs (clip, constraint check on the
+// pre-state, penalties, critical shutdown: base.py:157-213).
+// =================================================================================
+#include "nig_spec_plants.inc"
+constexpr int SPEC_MAX_NP = 15, SPEC_MAX_A = 10;
+struct spec_plant_t {
+    int np, na;
+    float y0[SPEC_MAX_NP], sd0[SPEC_MAX_NP], k[SPEC_MAX_NP], amb[SPEC_MAX_NP], cpl[SPEC_MAX_NP];
+    int cidx[SPEC_MAX_NP];
+    float ymin[SPEC_MAX_NP], ymax[SPEC_MAX_NP], sp[SPEC_MAX_NP], w[SPEC_MAX_NP];
+    float G[SPEC_MAX_NP][SPEC_MAX_A];
+    float rate[SPEC_MAX_A], ecost[SPEC_MAX_A];
+    float nsd[2];
+    float we, wu, bonus;
+    int cfirst[3], ccount[3];
+    float clo[3], chi[3], pen[3];
+    int crit[3];
+    int d_idx;
+    float dlo, dhi;
+};
+// constexpr: every table access below has a compile-time index once the loops are unrolled, so the
+// numbers end up as instruction literals (no table in device memory)
+constexpr spec_plant_t NIG_SPEC_PLANTS[4] = {NIG_SPEC_PLANT_ROWS};
+constexpr int NIG_SPEC_NP[4] = {NIG_SPEC_NP_LIST}, NIG_SPEC_NA[4] = {NIG_SPEC_NA_LIST};
+constexpr int NIG_SPEC_MAXSTEPS[4] = {NIG_SPEC_MAXSTEPS_LIST};
+
+template <int K>
+struct SpecPlant {
+    static constexpr int NP = NIG_SPEC_NP[K], A = NIG_SPEC_NA[K], S = NP + A + 3, ID = 5 + K;
+    static constexpr int KS = 2, KR = NP, MAX_STEPS = NIG_SPEC_MAXSTEPS[K];
+    static constexpr int ROW_E = NP + A, ROW_ECUM = NP + A + 1, ROW_T = NP + A + 2;
+    static constexpr bool COMPACT_RESET = false, SHARED_STEP_BLOCK = false, CUSTOM_STEP = false, RET_F32 = true;
+    static constexpr int STEP_WAVES = 4, ROLLOUT_WAVES = (S > 24) ? 2 : 3;
+    using reward_t = float;
+    __device__ static constexpr float act_low(int) { return -1.0f; }
+    __device__ static constexpr float act_high(int) { return 1.0f; }
+    __device__ static constexpr float penalty(int k) { return NIG_SPEC_PLANTS[K].pen[k]; }
+    static constexpr uint32_t CRIT_MASK = (NIG_SPEC_PLANTS[K].crit[0] ? 1u : 0u) | (NIG_SPEC_PLANTS[K].crit[1] ? 2u : 0u) |
+                                          (NIG_SPEC_PLANTS[K].crit[2] ? 4u : 0u);
+
+    __device__ static void init(const double (&n)[KR], float (&s)[S])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) s[i] = (float)((double)P.y0[i] + n[i]);
+#pragma unroll
+        for (int j = 0; j < A; ++j) s[NP + j] = 0.5f;
+        s[ROW_E] = 0.0f; s[ROW_ECUM] = 0.0f; s[ROW_T] = 0.0f;
+    }
+    __device__ static void draw_init(const RngKey &k, double (&n)[KR])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        float z[KR];
+        gen_normals<KR>(k, STREAM_RESET, z);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) n[i] = 0.0 + (double)P.sd0[i] * (double)z[i];
+    }
+    __device__ static void draw_step(const RngKey &k, double (&n)[KS])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        float z[KS];
+        gen_normals<KS>(k, STREAM_STEP, z);
+        n[0] = 0.0 + (double)P.nsd[0] * (double)z[0];
+        n[1] = 0.0 + (double)P.nsd[1] * (double)z[1];
+    }
+
+    // box constraint c: every row of [cfirst, cfirst + ccount) inside [clo, chi]; bit set = violated
+    __device__ static uint32_t violated(const float (&s)[S], const float (&)[A])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < S; ++r)
+                if (r >= P.cfirst[c] && r < P.cfirst[c] + P.ccount[c]) ok = ok && (P.clo[c] <= s[r]) && (s[r] <= P.chi[c]);
+            v |= ok ? 0u : (1u << c);
+        }
+        return v;
+    }
+
+    __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const double (&nz)[KS],
+                                    float dt32, double, float (&o)[S])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        float pn[A];
+        float e = 0.0f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {              // velocity-form actuators, clipped to [0, 1]
+            pn[j] = pymax(0.0f, pymin(1.0f, s[NP + j] + (P.rate[j] * a[j]) * dt32));
+            e = e + P.ecost[j] * pn[j];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float dy = (-P.k[i]) * (s[i] - P.amb[i]);
+#pragma unroll
+            for (int j = 0; j < A; ++j)
+                if (P.G[i][j] != 0.0f) dy = dy + P.G[i][j] * pn[j];
+            if (P.cpl[i] != 0.0f) dy = dy + P.cpl[i] * (s[P.cidx[i]] - s[i]);
+            if (i < KS) dy = dy + (float)nz[i];
+            o[i] = pymax(P.ymin[i], pymin(P.ymax[i], s[i] + dy * dt32));
+        }
+#pragma unroll
+        for (int j = 0; j < A; ++j) o[NP + j] = pn[j];
+        o[ROW_E] = e;
+        o[ROW_ECUM] = s[ROW_ECUM] + e * dt32;
+        o[ROW_T] = s[ROW_T] + dt32;
+    }
+
+    __device__ static float reward(const float (&n)[S], const float (&a)[A])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        float r = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (P.w[i] != 0.0f) r = r - P.w[i] * fabsf(n[i] - P.sp[i]);
+        r = r - P.we * n[ROW_E];
+        float ap = 0.0f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) ap = ap + fabsf(a[j]);
+        r = r - P.wu * ap;
+        bool ok = true;                            // bonus while constraint 0 holds on the new state
+#pragma unroll
+        for (int rr = 0; rr < S; ++rr)
+            if (rr >= P.cfirst[0] && rr < P.cfirst[0] + P.ccount[0]) ok = ok && (P.clo[0] <= n[rr]) && (n[rr] <= P.chi[0]);
+        return ok ? (r + P.bonus) : r;
+    }
+
+    __device__ static bool done(const float (&n)[S])
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        return (n[P.d_idx] < P.dlo) || (n[P.d_idx] > P.dhi);
+    }
+};
+using HVACControl = SpecPlant<0>;
+using WaterTreatment = SpecPlant<1>;
+using SteelAnnealing = SpecPlant<2>;
+using SupplyChain = SpecPlant<3>;
+
 // Result of one IndustrialEnv.step for one lane (filled by step_core or by an env's own step).
 template <class Env>
 struct StepResult {

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     __shared__ float s_init[COMPACT ? S * BLOCK : 1];
     __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
     __shared__ int s_cnt[COMPACT ? NWAVE : 1];
-    __shared__ v4f s_tr[OUT == 3 ? NWAVE : 1][OUT == 3 ? 64 * (S / 4) : 1];   // per-wave transpose of the row-major observation rows
+    __shared__ v4f s_tr[OUT == 3 ? NWAVE : 1][OUT == 3 ? 16 * S : 1];          // per-wave transpose of the row-major observation rows (64 x S floats)
     NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
@@ -521,9 +521,15 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (OUT == 3) {                  // stage this lane's row; read back transposed below
-            v4f *tr = s_tr[tid >> 6] + (tid & 63u) * (S / 4);
+            if constexpr (S % 4 == 0) {
+                v4f *tr = s_tr[tid >> 6] + (tid & 63u) * (S / 4);
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
+                for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
+            } else {
+                float *tr = reinterpret_cast<float *>(s_tr[tid >> 6]) + (tid & 63u) * S;
+#pragma unroll
+                for (int k = 0; k < S; ++k) tr[k] = n[k];
+            }
         }
         // Refill this buffer with the action of step it+DEPTH, issued BEFORE this step's stores: the
         // registers of `a` are dead by now (the load lands in place, no rotation of register sets),
@@ -546,16 +552,22 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
             const v4f *tr = s_tr[tid >> 6];
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
-            v4f v[S / 4];
+            constexpr int NV = (16 * S + 63) / 64;  // float4 pieces per lane: the wave's block is 64*S floats = 16*S float4
+            v4f v[NV];
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) v[k] = tr[lane + 64u * k];
+            for (int k = 0; k < NV; ++k) v[k] = tr[(16 * S % 64 == 0 || lane + 64u * k < 16u * S) ? lane + 64u * k : 0u];
             if (wave_env0 + 64u <= p.B) {          // wave-uniform: the whole wave exists
 #pragma unroll
-                for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, v[k]);
-            } else {
+                for (int k = 0; k < NV; ++k)
+                    if (16 * S % 64 == 0 || lane + 64u * k < 16u * S) stream_store(oo + lane + 64u * k, v[k]);
+            } else if constexpr (S % 4 == 0) {
 #pragma unroll
-                for (int k = 0; k < S / 4; ++k)
+                for (int k = 0; k < NV; ++k)
                     if (wave_env0 + (lane + 64u * k) / (unsigned)(S / 4) < p.B) stream_store(oo + lane + 64u * k, v[k]);
+            } else if (in_range) {                 // partial wave, rows not float4-sized: the lane's own row, dword by dword
+                float *row = obs_row + (size_t)lane * S;
+#pragma unroll
+                for (int k = 0; k < S; ++k) row[k] = n[k];
             }
         }
         if (in_range) {
@@ -793,8 +805,13 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
         policy_action<Env>(q.pol, s, key, integ, eprev, a);
         if (q.obs_out) {
             float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + tid) * S;
+            if constexpr (S % 4 == 0) {
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+                for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+            } else {                               // rows that are not a multiple of 16 bytes: dword stores
+#pragma unroll
+                for (int k = 0; k < S; ++k) oo[k] = s[k];
+            }
         }
         if (q.act_out) {
             float *ao = q.act_out + (size_t)it * q.act_step_stride + base;
@@ -975,8 +992,13 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
         if (writer && !frozen) {
             if (q.obs_out) {
                 float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)li * S;
+                if constexpr (S % 4 == 0) {
 #pragma unroll
-                for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+                    for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) oo[k] = s[k];
+                }
             }
             if (q.act_out) {
                 float *ao = q.act_out + (size_t)it * q.act_step_stride;
@@ -1224,9 +1246,16 @@ static const nig_env_spec SPECS[NIG_NUM_ENVS] = {
     /* Advanced envs: 4 / 3 safety-metric conditions, no penalties through the base loop, deterministic */
     {20, 6, 4, 1000, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
     {32, 8, 3, 500, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
+    /* build-specified plants (spec_plants.py): dims and constraint tables come from the generated data */
+#define NIG_SPEC_ROW(K) {SpecPlant<K>::S, SpecPlant<K>::A, 3, SpecPlant<K>::MAX_STEPS, SpecPlant<K>::KS, SpecPlant<K>::KR, 0.1, \
+                         {NIG_SPEC_PLANTS[K].pen[0], NIG_SPEC_PLANTS[K].pen[1], NIG_SPEC_PLANTS[K].pen[2]},                    \
+                         {NIG_SPEC_PLANTS[K].crit[0], NIG_SPEC_PLANTS[K].crit[1], NIG_SPEC_PLANTS[K].crit[2]}, 1}
+    NIG_SPEC_ROW(0), NIG_SPEC_ROW(1), NIG_SPEC_ROW(2), NIG_SPEC_ROW(3),
+#undef NIG_SPEC_ROW
 };
 static const char *NAMES[NIG_NUM_ENVS] = {"ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0",
-                                          "AdvancedChemicalReactor-v0", "AdvancedPowerGrid-v0"};
+                                          "AdvancedChemicalReactor-v0", "AdvancedPowerGrid-v0",
+                                          "HVACControl-v0", "WaterTreatment-v0", "SteelAnnealing-v0", "SupplyChain-v0"};
 
 // run `F<Env>(args...)` for the env type behind a run-time id
 #define NIG_DISPATCH_ENV(env_id, CALL)                                      \
@@ -1235,7 +1264,11 @@ static const char *NAMES[NIG_NUM_ENVS] = {"ChemicalReactor-v0", "PowerGrid-v0", 
     case NIG_ENV_POWER_GRID: { using E = PowerGrid; CALL; } break;                      \
     case NIG_ENV_ROBOT_ASSEMBLY: { using E = RobotAssembly; CALL; } break;              \
     case NIG_ENV_ADV_CHEMICAL_REACTOR: { using E = AdvancedChemicalReactor; CALL; } break; \
-    default: { using E = AdvancedPowerGrid; CALL; } break;                  \
+    case NIG_ENV_ADV_POWER_GRID: { using E = AdvancedPowerGrid; CALL; } break;          \
+    case NIG_ENV_HVAC_CONTROL: { using E = HVACControl; CALL; } break;                  \
+    case NIG_ENV_WATER_TREATMENT: { using E = WaterTreatment; CALL; } break;            \
+    case NIG_ENV_STEEL_ANNEALING: { using E = SteelAnnealing; CALL; } break;            \
+    default: { using E = SupplyChain; CALL; } break;                        \
     }
 
 template <class Env>
@@ -1243,6 +1276,14 @@ static void launch_reset(const ResetArgs &a, bool parity, hipStream_t st)
 {
     if (parity) hipLaunchKernelGGL((reset_kernel<Env, true>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((reset_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
+}
+
+// the MFMA actor exists for even state dims and at most 8 actions (nig_set_mlp_policy refuses the others,
+// so a handle of such an env never gets here with a weight stream installed)
+template <class Env>
+static void launch_mlp(const MlpArgs &q, unsigned grid, hipStream_t st)
+{
+    if constexpr (Env::S % 2 == 0 && Env::A <= 8) hipLaunchKernelGGL((rollout_mlp_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, q);
 }
 
 template <class Env>
@@ -1671,7 +1712,7 @@ int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t 
     q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((h->B + BLOCK / 2 - 1) / (BLOCK / 2));     // 32 envs per wave, 128 per block
-    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_mlp_kernel<E>), dim3(grid), dim3(BLOCK), 0, st, q));
+    NIG_DISPATCH_ENV(h->env, launch_mlp<E>(q, grid, st));
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;

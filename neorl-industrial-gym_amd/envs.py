@@ -410,3 +410,48 @@ class AdvancedPowerGridEnv(_AdvancedEnv):
         return {"system_frequency": float(np.sum(obs[16:20] * H) / np.sum(H)),
                 "total_generation": float(np.sum(obs[20:24])), "total_load": float(np.sum(obs[24:28])),
                 "emergency_active": bool(np.asarray(action)[7] > 0.5), "load_shedding_amount": float(np.asarray(action)[6])}
+
+
+class _SpecPlantEnv(IndustrialEnv):
+    """The four README-only environments (README.md:28-32): BUILD-SPECIFIED plants, no reference
+    implementation exists (spec_plants.py holds the model and its numbers).  Same base-class surface
+    as the three real envs: clip, constraint check on the pre-state, penalties, critical shutdown."""
+    _PLANT = None
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        P = self._PLANT
+        self.variable_names = [y["name"] for y in P["y"]] + [a["name"] for a in P["act"]] + \
+            ["effort", "effort_integral", "elapsed_time"]
+
+    def _builtin_constraints(self):
+        def box(first, count, lo, hi):
+            return lambda state, action: bool(np.all((np.asarray(state)[first:first + count] >= f32(lo)) &
+                                                     (np.asarray(state)[first:first + count] <= f32(hi))))
+        return [SafetyConstraint(name, box(first, count, lo, hi), float(pen), bool(crit),
+                                 f"rows {first}..{first + count - 1} within [{lo}, {hi}] (build-specified)")
+                for (name, first, count, lo, hi, pen, crit) in self._PLANT["constraints"]]
+
+    def _draw_reset_noise(self):
+        return np.array([np.random.normal(0, y["sd0"]) for y in self._PLANT["y"]], dtype=np.float64)
+
+    def _draw_step_noise(self):
+        sd = self._PLANT["noise_sd"]
+        return np.array([np.random.normal(0, sd[0]), np.random.normal(0, sd[1])], dtype=np.float64)
+
+    def _get_safety_info(self, state):
+        return {"safety_metrics": {c[0]: bool(chk.check_fn(state, None)) for c, chk in zip(self._PLANT["constraints"], self._builtin)},
+                "constraint_values": {n: float(state[i]) for i, n in enumerate(self.variable_names)}}
+
+
+def _spec_env(name, plant):
+    return type(name, (_SpecPlantEnv,), {"ENV_ID": plant["name"], "_PLANT": plant,
+                                         "__doc__": f"{plant['name']}: build-specified plant (README-only upstream)."})
+
+
+from .spec_plants import HVAC as _HVAC, STEEL as _STEEL, SUPPLY as _SUPPLY, WATER as _WATER   # noqa: E402
+
+HVACControlEnv = _spec_env("HVACControlEnv", _HVAC)
+WaterTreatmentEnv = _spec_env("WaterTreatmentEnv", _WATER)
+SteelAnnealingEnv = _spec_env("SteelAnnealingEnv", _STEEL)
+SupplyChainEnv = _spec_env("SupplyChainEnv", _SUPPLY)

@@ -27,7 +27,7 @@ class DevicePolicy:
     def __init__(self, state_dim: int, action_dim: int, kind: int = _lib.POLICY_AFFINE, W=None, b=None, sigma=None,
                  half_range=None, p_uniform: float = 0.0, uniform_range: float = 1.0, clip=(-np.inf, np.inf),
                  kp: float = 0.0, ki: float = 0.0, kd: float = 0.0, setpoint=None):
-        assert state_dim <= 32 and action_dim <= 8
+        assert state_dim <= 32 and action_dim <= 10      # NIG_MAX_STATE_DIM / NIG_MAX_ACTION_DIM (include/nig.h)
         self.state_dim, self.action_dim, self.kind = state_dim, action_dim, kind
         z = lambda: np.zeros(action_dim, dtype=f32)     # noqa: E731
         self.W = np.zeros((action_dim, state_dim), dtype=f32) if W is None else np.asarray(W, dtype=f32)

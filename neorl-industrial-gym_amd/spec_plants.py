@@ -1,0 +1,209 @@
+"""The four README-only environments (HVACControl, WaterTreatment, SteelAnnealing, SupplyChain).
+
+The reference lists them in its README table (README.md:24-32: name, state/action dims, the
+names of their safety constraints) and ships NO implementation -- no dynamics, no reward, no
+constraint thresholds.  There is nothing to be equal to, so these are BUILD-SPECIFIED plants,
+labelled as such everywhere: parity with the reference is undefined for them.  They exist so the
+BASELINE "all 7 envs, mixed batch" configuration runs the seven README environments.
+
+One plant family covers all four: NP process variables y_i with first-order relaxation to an
+ambient value, a linear coupling to one other variable and linear actuator gains; A actuators
+p_j in [0,1] driven in velocity form by the action (the way a PLC output block integrates a PID
+increment); three accounting rows (instantaneous effort, its integral, elapsed time):
+
+    p_j'  = clip(p_j + rate_j * a_j * dt, 0, 1)
+    dy_i  = -k_i (y_i - amb_i) + sum_j G_ij p_j' + cpl_i (y_cidx_i - y_i)  (+ noise_i for i < 2)
+    y_i'  = clip(y_i + dy_i * dt, ymin_i, ymax_i)
+    e'    = sum_j ecost_j p_j';   E' = E + e' dt;   t' = t + dt
+    reward = -sum_i w_i |y_i' - sp_i| - we e' - wu sum_j |a_j|  (+ bonus while constraint 0 holds)
+
+State layout: [y_0..y_NP-1, p_0..p_A-1, e, E, t], all float32, evaluated in exactly this order
+with one rounding per operation (csrc/nig_envs.hpp SpecPlant<K>; the tests' CPU restatement mirrors it).
+Each safety constraint is a box over a run of state rows.
+
+This file is the single source of the numbers: `python spec_plants.py` regenerates
+csrc/nig_spec_plants.inc and oracle/nig_spec_plants.inc (tests check they are current).
+"""
+import os
+
+INF = 1.0e30
+MAX_NP, MAX_A = 15, 10
+
+
+def _plant(name, y, act, noise_sd, we, wu, bonus, constraints, done, max_steps=1000):
+    """y: list of dicts (process variables), act: list of dicts (actuators)."""
+    return dict(name=name, y=y, act=act, noise_sd=noise_sd, we=we, wu=wu, bonus=bonus,
+                constraints=constraints, done=done, max_steps=max_steps)
+
+
+def _y(name, y0, sd0, k, amb, sp, w, lo, hi, gains=None, cpl=0.0, cidx=None):
+    return dict(name=name, y0=y0, sd0=sd0, k=k, amb=amb, sp=sp, w=w, lo=lo, hi=hi, gains=gains or {}, cpl=cpl, cidx=cidx)
+
+
+def _a(name, rate, ecost):
+    return dict(name=name, rate=rate, ecost=ecost)
+
+
+def _zones(n, prefix, **kw):
+    return [_y(f"{prefix}{i + 1}", **kw) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------
+# HVACControl-v0: 18 / 5, constraints "Energy, Comfort" (README.md:28)
+# ---------------------------------------------------------------------------------------------
+_hvac_y = []
+for i in range(4):   # zone temperatures [degC]: hot ambient, cooled by fan + chiller, warmed by reheat
+    _hvac_y.append(_y(f"zone_temp_{i + 1}", 23.0, 1.0, 0.05, 30.0 + i, 22.5, 1.0, -10.0, 60.0,
+                      {"fan": -0.5, "chiller": -0.7 - 0.05 * i, "reheat": 0.4}, cpl=0.02, cidx=(i + 1) % 4))
+for i in range(4):   # zone relative humidity [%]
+    _hvac_y.append(_y(f"zone_rh_{i + 1}", 50.0, 3.0, 0.03, 60.0, 45.0, 0.05, 0.0, 100.0,
+                      {"chiller": -1.2, "humidifier": 0.3, "damper": 0.1 * i}, cpl=0.01, cidx=4 + (i + 1) % 4))
+_hvac_y.append(_y("supply_air_temp", 16.0, 1.0, 0.5, 25.0, 14.0, 0.0, -20.0, 60.0, {"chiller": -14.0, "reheat": 3.0}))
+_hvac_y.append(_y("chilled_water_temp", 8.0, 0.5, 0.2, 15.0, 7.0, 0.0, 0.0, 30.0, {"chiller": -3.2}))
+HVAC = _plant("HVACControl-v0", _hvac_y,
+              [_a("fan", 0.5, 10.0), _a("damper", 0.5, 1.0), _a("chiller", 0.4, 40.0), _a("reheat", 0.5, 15.0),
+               _a("humidifier", 0.5, 5.0)],
+              noise_sd=(0.3, 0.3), we=0.05, wu=0.1, bonus=2.0,
+              constraints=[("comfort_band", 0, 4, 19.0, 26.0, -30.0, False),
+                           ("energy_limit", 15, 1, -INF, 55.0, -20.0, False),
+                           ("supply_air_freeze", 8, 1, 4.0, 40.0, -100.0, True)],
+              done=(0, 10.0, 38.0))
+
+# ---------------------------------------------------------------------------------------------
+# WaterTreatment-v0: 15 / 4, constraints "pH, Turbidity" (README.md:29)
+# ---------------------------------------------------------------------------------------------
+WATER = _plant("WaterTreatment-v0", [
+    _y("ph", 7.0, 0.1, 0.1, 7.5, 7.0, 5.0, 0.0, 14.0, {"ph_adjust": -0.1}),
+    _y("turbidity_ntu", 0.6, 0.1, 0.2, 8.0, 0.3, 2.0, 0.0, 100.0, {"coagulant": -3.0}, cpl=0.002, cidx=3),
+    _y("chlorine_mg_l", 1.0, 0.1, 0.3, 0.0, 1.0, 2.0, 0.0, 10.0, {"chlorine": 0.6}),
+    _y("flow", 50.0, 2.0, 0.5, 0.0, 50.0, 0.05, 0.0, 120.0, {"pump": 50.0}),
+    _y("tank_level", 60.0, 3.0, 0.02, 50.0, 60.0, 0.1, 0.0, 100.0, {"pump": 0.4}),
+    _y("coagulant_residual", 0.5, 0.05, 0.3, 0.0, 0.5, 0.0, 0.0, 5.0, {"coagulant": 0.3}),
+    _y("filter_headloss", 1.0, 0.1, 0.05, 0.5, 1.0, 0.2, 0.0, 10.0, {"pump": 0.05}, cpl=0.01, cidx=1),
+    _y("water_temp", 15.0, 1.0, 0.01, 15.0, 15.0, 0.0, 0.0, 40.0),
+], [_a("coagulant", 0.4, 3.0), _a("ph_adjust", 0.4, 2.0), _a("chlorine", 0.4, 2.0), _a("pump", 0.3, 25.0)],
+    noise_sd=(0.05, 0.5), we=0.1, wu=0.1, bonus=3.0,
+    constraints=[("ph_range", 0, 1, 6.5, 8.5, -100.0, True),
+                 ("turbidity_limit", 1, 1, -INF, 1.0, -50.0, False),
+                 ("chlorine_residual", 2, 1, 0.2, 4.0, -25.0, False)],
+    done=(4, 5.0, 95.0))
+
+# ---------------------------------------------------------------------------------------------
+# SteelAnnealing-v0: 20 / 6, constraint "Temperature Profile" (README.md:30)
+# ---------------------------------------------------------------------------------------------
+_prof = [650.0, 720.0, 780.0, 800.0, 700.0, 450.0]
+_burn = [{"burner_1": 35.0}, {"burner_1": 12.0, "burner_2": 30.0}, {"burner_2": 18.0, "burner_3": 30.0},
+         {"burner_3": 20.0, "burner_4": 30.0}, {"burner_4": 50.0, "cooling_fan": -10.0},
+         {"burner_4": 25.0, "cooling_fan": -10.0}]
+_steel_y = [_y(f"zone_temp_{i + 1}", _prof[i], 10.0, 0.05, 300.0, _prof[i], 0.02, 20.0, 1200.0, _burn[i],
+               cpl=0.01, cidx=min(i + 1, 5)) for i in range(6)]
+_steel_y += [_y("strip_temp_soak", 700.0, 10.0, 0.0, 0.0, 720.0, 0.05, 20.0, 1200.0, cpl=0.3, cidx=1),
+             _y("strip_temp_peak", 780.0, 10.0, 0.0, 0.0, 800.0, 0.05, 20.0, 1200.0, cpl=0.3, cidx=3),
+             _y("strip_temp_exit", 460.0, 10.0, 0.0, 0.0, 450.0, 0.05, 20.0, 1200.0, cpl=0.3, cidx=5),
+             _y("line_speed", 50.0, 2.0, 0.5, 0.0, 50.0, 0.1, 0.0, 120.0, {"line_drive": 50.0}),
+             _y("atmosphere_h2", 5.0, 0.2, 0.1, 5.0, 5.0, 0.0, 0.0, 20.0)]
+STEEL = _plant("SteelAnnealing-v0", _steel_y,
+               [_a("burner_1", 0.3, 30.0), _a("burner_2", 0.3, 30.0), _a("burner_3", 0.3, 30.0), _a("burner_4", 0.3, 30.0),
+                _a("cooling_fan", 0.5, 8.0), _a("line_drive", 0.4, 12.0)],
+               noise_sd=(20.0, 20.0), we=0.02, wu=0.1, bonus=5.0,
+               constraints=[("temperature_profile", 0, 6, 380.0, 860.0, -100.0, True),
+                            ("strip_exit_temp", 8, 1, 300.0, 600.0, -50.0, False),
+                            ("line_speed", 9, 1, 10.0, 90.0, -25.0, False)],
+               done=(7, 100.0, 950.0))
+
+# ---------------------------------------------------------------------------------------------
+# SupplyChain-v0: 28 / 10, constraints "Inventory, Delays" (README.md:32)
+# ---------------------------------------------------------------------------------------------
+_sc_y = [_y(f"inventory_{i + 1}", 100.0, 10.0, 0.1, 0.0, 100.0, 0.02, 0.0, 500.0, {f"order_{i + 1}": 20.0},
+            cpl=0.01, cidx=(i + 1) % 10) for i in range(10)]
+_sc_y += [_y(f"lead_time_{m + 1}", 4.0, 0.3, 0.2, 1.0, 3.0, 0.5, 0.0, 30.0,
+             {f"order_{2 * m + 1}": 0.6, f"order_{2 * m + 2}": 0.6}) for m in range(5)]
+SUPPLY = _plant("SupplyChain-v0", _sc_y, [_a(f"order_{j + 1}", 0.5, 2.0) for j in range(10)],
+                noise_sd=(30.0, 30.0), we=0.1, wu=0.05, bonus=2.0,
+                constraints=[("inventory_bounds", 0, 10, 20.0, 250.0, -30.0, False),
+                             ("delivery_delays", 10, 5, -INF, 6.0, -40.0, False),
+                             ("stockout", 0, 10, 5.0, INF, -100.0, True)],
+                done=(0, 0.5, 400.0))
+
+PLANTS = [HVAC, WATER, STEEL, SUPPLY]
+FIRST_ENV_ID = 5      # include/nig.h NIG_ENV_HVAC_CONTROL
+
+
+def dims(p):
+    np_, na = len(p["y"]), len(p["act"])
+    return np_, na, np_ + na + 3
+
+
+def _f(x):
+    import numpy as np
+    v = float(np.float32(x))
+    if v >= 9.0e29:
+        return "1.0e30f"
+    if v <= -9.0e29:
+        return "-1.0e30f"
+    s = repr(float(np.format_float_positional(np.float32(v), unique=True, trim="0")))
+    return (s if ("." in s or "e" in s) else s + ".0") + "f"
+
+
+def _row(vals, n, fmt=_f):
+    vals = list(vals) + [0] * (n - len(vals))
+    return "{" + ", ".join(fmt(v) for v in vals) + "}"
+
+
+def emit_inc():
+    """Positional aggregate initialisers of `spec_plant_t` (same field order in csrc and oracle)."""
+    out = ["/* GENERATED by neorl-industrial-gym_amd/spec_plants.py -- do not edit.  Build-specified plants of the",
+           " * four README-only environments (no reference implementation exists; see that file). */",
+           "#define NIG_SPEC_NP_LIST " + ", ".join(str(dims(p)[0]) for p in PLANTS),
+           "#define NIG_SPEC_NA_LIST " + ", ".join(str(dims(p)[1]) for p in PLANTS),
+           "#define NIG_SPEC_MAXSTEPS_LIST " + ", ".join(str(p["max_steps"]) for p in PLANTS),
+           "#define NIG_SPEC_PLANT_ROWS \\"]
+    rows = []
+    for p in PLANTS:
+        np_, na, _ = dims(p)
+        aidx = {a["name"]: j for j, a in enumerate(p["act"])}
+        Y = p["y"]
+        i2 = lambda v: str(int(v))
+        G = []
+        for y in Y:
+            g = [0.0] * na
+            for k, v in y["gains"].items():
+                g[aidx[k]] = v
+            G.append(_row(g, MAX_A))
+        G += [_row([], MAX_A)] * (MAX_NP - np_)
+        c = p["constraints"]
+        fields = [
+            f"{np_}, {na}",
+            _row([y["y0"] for y in Y], MAX_NP), _row([y["sd0"] for y in Y], MAX_NP),
+            _row([y["k"] for y in Y], MAX_NP), _row([y["amb"] for y in Y], MAX_NP),
+            _row([y["cpl"] for y in Y], MAX_NP),
+            _row([(y["cidx"] if y["cidx"] is not None else i) for i, y in enumerate(Y)], MAX_NP, i2),
+            _row([y["lo"] for y in Y], MAX_NP), _row([y["hi"] for y in Y], MAX_NP),
+            _row([y["sp"] for y in Y], MAX_NP), _row([y["w"] for y in Y], MAX_NP),
+            "{" + ", ".join(G) + "}",
+            _row([a["rate"] for a in p["act"]], MAX_A), _row([a["ecost"] for a in p["act"]], MAX_A),
+            _row(p["noise_sd"], 2), f"{_f(p['we'])}, {_f(p['wu'])}, {_f(p['bonus'])}",
+            _row([x[1] for x in c], 3, i2), _row([x[2] for x in c], 3, i2),
+            _row([x[3] for x in c], 3), _row([x[4] for x in c], 3), _row([x[5] for x in c], 3),
+            _row([1 if x[6] else 0 for x in c], 3, i2),
+            f"{p['done'][0]}, {_f(p['done'][1])}, {_f(p['done'][2])}",
+        ]
+        rows.append("    /* " + p["name"] + " */ {" + ", \\\n      ".join(fields) + "}")
+    out.append(", \\\n".join(rows))
+    return "\n".join(out) + "\n"
+
+
+def write_inc():
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = emit_inc()
+    for path in (os.path.join(here, "csrc", "nig_spec_plants.inc"),
+                 os.path.join(os.path.dirname(here), "oracle", "nig_spec_plants.inc")):
+        with open(path, "w") as f:
+            f.write(text)
+    return text
+
+
+if __name__ == "__main__":
+    write_inc()
+    for p in PLANTS:
+        print(p["name"], dims(p))

@@ -6,8 +6,8 @@ import torch
 
 from . import _lib
 from .batched import BatchedIndustrialEnv
-from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalReactorEnv, PowerGridEnv,
-                   RobotAssemblyEnv)
+from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalReactorEnv, HVACControlEnv, PowerGridEnv,
+                   RobotAssemblyEnv, SteelAnnealingEnv, SupplyChainEnv, WaterTreatmentEnv)
 from .parallel import all_reduce_partial, metrics_from_partial
 
 _REGISTRY = {
@@ -16,6 +16,11 @@ _REGISTRY = {
     "RobotAssembly-v0": RobotAssemblyEnv,
     "AdvancedChemicalReactor-v0": AdvancedChemicalReactorEnv,     # utils.py:30-31: registered upstream but
     "AdvancedPowerGrid-v0": AdvancedPowerGridEnv,                 # not instantiable there (candidate rows)
+    # README.md:28-32 lists these four; upstream ni.make() raises for them (no implementation).  Build-specified.
+    "HVACControl-v0": HVACControlEnv,
+    "WaterTreatment-v0": WaterTreatmentEnv,
+    "SteelAnnealing-v0": SteelAnnealingEnv,
+    "SupplyChain-v0": SupplyChainEnv,
 }
 
 

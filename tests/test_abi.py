@@ -44,6 +44,14 @@ def test_static_queries_match_reference_constants(oracle):
         sp, osp = ni._lib.env_spec(eid), oracle.spec(key)
         assert (sp.state_dim, sp.action_dim, sp.max_episode_steps, sp.k_step, sp.k_reset) == (S, A, T, 0, 0)
         assert (osp.state_dim, osp.action_dim, osp.max_episode_steps) == (S, A, T) and sp.n_constraints == osp.n_constraints
+    # README-only upstream (README.md:28-32): build-specified plants with the README's dims
+    for k, (name, S, A) in enumerate([("HVACControl-v0", 18, 5), ("WaterTreatment-v0", 15, 4),
+                                      ("SteelAnnealing-v0", 20, 6), ("SupplyChain-v0", 28, 10)]):
+        assert L.nig_env_id(name.encode()) == 5 + k
+        sp, osp = ni._lib.env_spec(5 + k), oracle.spec(name)
+        assert (sp.state_dim, sp.action_dim, sp.n_constraints, sp.k_step, sp.k_reset) == (S, A, 3, 2, S - A - 3)
+        assert (osp.state_dim, osp.action_dim, osp.k_step, osp.k_reset) == (S, A, 2, S - A - 3)
+        assert list(sp.penalty) == list(osp.penalty) and list(sp.critical) == list(osp.critical)
     assert L.nig_env_id(b"nope") == -1
 
 
@@ -56,7 +64,7 @@ def test_layout_query():
     lay2 = ni._lib.layout_query(1, 1000, 0)
     assert lay2.off_tally == -1 and lay2.off_ep_return == -1 and lay2.bytes < lay.bytes
     with pytest.raises(ni._lib.NigError):
-        ni._lib.layout_query(7, 10, 0)
+        ni._lib.layout_query(9, 10, 0)
     with pytest.raises(ni._lib.NigError):
         ni._lib.layout_query(0, 0, 0)
 
