@@ -301,14 +301,24 @@ def main():
         dist.destroy_process_group()
 
 
+MIXED7 = [("ChemicalReactor-v0", 12, 3, "reference"), ("RobotAssembly-v0", 24, 7, "reference"),
+          ("HVACControl-v0", 18, 5, "build-specified"), ("WaterTreatment-v0", 15, 4, "build-specified"),
+          ("SteelAnnealing-v0", 20, 6, "build-specified"), ("PowerGrid-v0", 32, 8, "reference"),
+          ("SupplyChain-v0", 28, 10, "build-specified")]
+
+
 def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
-    """BASELINE config 4: every (oracle-backed) env type in ONE padded SoA batch of --batch lanes
-    (default 1 048 576), contiguous 256-aligned segments, one rollout kernel per segment on its own
-    stream.  Reports total and per-env throughput; the HBM figure is the lane-weighted fused-rollout
-    byte count with reward+flags outputs."""
+    """BASELINE config 4: the README's seven environments (README.md:24-32) in ONE padded SoA batch of
+    --batch lanes (default 1 048 576), contiguous 256-aligned segments of equal size, one rollout
+    kernel per segment on its own stream.  Three of the seven exist upstream and are parity-checked
+    against the reference; four are README-only there and run build-specified plants (flagged per env).
+    Reports total and per-env throughput; the HBM figure is the lane-weighted fused-rollout byte count
+    with reward+flags outputs."""
     B = args.batch or 1048576
-    per = (B // 3) // 256 * 256
-    counts = [(ENVS["cr"], B - 2 * per), (ENVS["pg"], per), (ENVS["ra"], per)]
+    per = (B // 7) // 256 * 256
+    counts = [(name, per if i else B - 6 * per) for i, (name, _, _, _) in enumerate(MIXED7)]
+    dims = {name: (S, A) for name, S, A, _ in MIXED7}
+    origin = {name: o for name, _, _, o in MIXED7}
     mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B)
     R, P = min(args.ring, 16), max(1, min(args.plan_steps, args.steps))
     ring = torch.zeros(R, mix.A_max, mix.ld, dtype=torch.float32, device=device)
@@ -343,22 +353,22 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     # per-env rate measured separately on its own segment size (same kernels)
     per_env = {}
     for (name, n), seg in zip(counts, mix.envs):
-        k = [kk for kk, v in ENVS.items() if v == name][0]
-        sring = ring[:, :seg.action_dim, :]
         o = mix.offsets[mix.envs.index(seg)]
+        reps = max(1, args.steps // P // 4)
         torch.cuda.synchronize(); c0 = time.perf_counter()
-        for _ in range(max(1, args.steps // P // 4)):
+        for _ in range(reps):
             seg.rollout(P, ring[:, :seg.action_dim, o:o + n], rew[:, o:o + n], fl[:, o:o + n])
         torch.cuda.synchronize()
-        per_env[k] = {"lanes": n, "env_steps_per_s": max(1, args.steps // P // 4) * P * n / (time.perf_counter() - c0),
-                      "oracle_parity": True}
+        per_env[name] = {"lanes": n, "state_dim": dims[name][0], "action_dim": dims[name][1],
+                         "env_steps_per_s": reps * P * n / (time.perf_counter() - c0),
+                         "dynamics": origin[name], "reference_parity": origin[name] == "reference"}
     if rank == 0:
-        bytes_launch = sum((4 * DIMS[k][1] + 8) * v["lanes"] for k, v in per_env.items()) * P
+        bytes_launch = sum((4 * v["action_dim"] + 8) * v["lanes"] for v in per_env.values()) * P
         n_launch = args.steps // P + (1 if args.steps % P else 0)
         launch_us = dev_ms * 1e3 / n_launch
         achieved = bytes_launch / (launch_us * 1e-6) / 1e9
         print(json.dumps({
-            "metric": "env-steps/sec (whole node), all oracle-backed envs mixed-batch", "value": args.steps * B * world / wall,
+            "metric": "env-steps/sec (whole node), all 7 envs mixed-batch", "value": args.steps * B * world / wall,
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -366,7 +376,7 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
                                    + ", ".join(f"{n} x {e}" for e, n in counts) + f"; fused rollout, {P} env.step per launch, "
                                    "reward+flags outputs", "batch_per_gpu": B, "segments": counts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<*,1> x3 (concurrent streams)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<*,1> x7 (concurrent streams)",
                          "alg_bytes_per_launch": bytes_launch, "launch_us": launch_us,
                          "bytes_model": "fused-rollout figure: action read + reward + flag word per env-step, lane-weighted"},
             "per_env": per_env}))
