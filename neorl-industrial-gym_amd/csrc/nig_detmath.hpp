@@ -174,8 +174,10 @@ constexpr uint32_t STREAM_POLICY = 0xC0000000u;   // +0: mixture draw, +1..: nor
 struct u32x4 { uint32_t x, y, z, w; };
 
 // 32x32 -> 64-bit product in ONE instruction.  hipcc lowers "(uint64_t)a * b" to a v_mul_hi_u32 +
-// v_mul_lo_u32 pair; both are quarter-rate on CDNA, and the 20 pairs of a Philox call were ~36 % of
-// the ChemicalReactor step's issue cycles.  v_mad_u64_u32 yields hi and lo together.
+// v_mul_lo_u32 pair (40 instructions per Philox call); v_mad_u64_u32 yields hi and lo together (20).
+// (Measured on gfx950: the wide multiply issues like an ordinary VALU instruction -- replacing five of
+// PowerGrid's six blocks per step with an add/xor/rotate stream of equal instruction count changed
+// nothing beyond the count.)
 __device__ __forceinline__ void mulhilo32(uint32_t m, uint32_t x, uint32_t &hi, uint32_t &lo)
 {
     uint64_t r;
