@@ -216,7 +216,7 @@ struct RngKey {
 // (0, 0.5); the piece is picked by the float32 exponent and top 5 mantissa bits of f = m + 0.5
 // (24 binades x 32 = 768 pieces, narrower towards the tail), the low 18 mantissa bits are the
 // position inside the piece.  Max |error| 4.8e-7 (the float32 grid at z ~ 5); |z| <= 5.42.
-// ~17 VALU + one 16-byte LDS read, against ~43 VALU per normal for a polynomial Box-Muller
+// ~14 VALU + one 16-byte LDS read, against ~43 VALU per normal for a polynomial Box-Muller
 // (log + sqrt + sincos) -- PowerGrid draws 23 normals per env-step.  The table is generated data
 // (gen_probit_table.py); the oracle compiles the same data and runs the same float32 sequence.
 __device__ const float4 NIG_PROBIT[768] = {
@@ -239,9 +239,9 @@ __device__ __forceinline__ ProbitFetch probit_fetch(uint32_t word, const float4 
 
 __device__ __forceinline__ float probit_eval(const ProbitFetch &f)
 {
-    float z = f.c.w * f.t + f.c.z;
-    z = z * f.t + f.c.y;
-    z = z * f.t + f.c.x;
+    float z = __builtin_fmaf(f.c.w, f.t, f.c.z);           // Horner in three fused steps (the generator is this
+    z = __builtin_fmaf(z, f.t, f.c.y);                     // build's own spec; the CPU restatement fuses too)
+    z = __builtin_fmaf(z, f.t, f.c.x);
     return (f.v & 0x800000u) ? -z : z;
 }
 
