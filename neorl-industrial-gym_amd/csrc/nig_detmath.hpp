@@ -32,21 +32,21 @@ __device__ __forceinline__ float bits_f32(uint32_t u) { return __uint_as_float(u
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
 
 // e^x, float32, Cephes-style: k = floor(x*log2e + 1/2), two-constant Cody-Waite, degree-5
-// polynomial, exact two-step scaling.  <= 1 ulp-ish; stands in for np.exp on float32
+// polynomial in fused multiply-adds, exact two-step scaling.  <= 1 ulp-ish; stands in for np.exp on float32
 // (chemical_reactor.py:177), which itself is only good to ~2 ulp.
 __device__ __forceinline__ float det_expf(float x)
 {
-    float fk = floorf(x * 1.44269504088896341f + 0.5f);
-    float r = x - fk * 0.693359375f;
-    r = r - fk * -2.12194440e-4f;
+    float fk = floorf(__builtin_fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(-fk, 0.693359375f, x);
+    r = __builtin_fmaf(-fk, -2.12194440e-4f, r);
     const float z = r * r;
     float p = 1.9875691500e-4f;
-    p = p * r + 1.3981999507e-3f;
-    p = p * r + 8.3334519073e-3f;
-    p = p * r + 4.1665795894e-2f;
-    p = p * r + 1.6666665459e-1f;
-    p = p * r + 5.0000001201e-1f;
-    p = p * z + r;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    p = __builtin_fmaf(p, z, r);
     p = p + 1.0f;
     // clamp only affects the out-of-range inputs that are overridden below
     fk = fminf(fmaxf(fk, -200.0f), 200.0f);
@@ -135,24 +135,24 @@ __device__ __forceinline__ float det_sinf(float x)
 // float64 scalars (robot_assembly.py:103-107).
 __device__ __forceinline__ void det_sincos(double x, double &s, double &c)
 {
-    const double fk = floor(x * 0.63661977236758134308 + 0.5);
-    double r = x - fk * 1.57079632673412561417e+00;
-    r = r - fk * 6.07710050650619224932e-11;
+    const double fk = floor(__builtin_fma(x, 0.63661977236758134308, 0.5));
+    double r = __builtin_fma(-fk, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-fk, 6.07710050650619224932e-11, r);
     const double z = r * r;
     double ps = 1.58969099521155010221e-10;
-    ps = ps * z + -2.50507602534068634195e-08;
-    ps = ps * z + 2.75573137070700676789e-06;
-    ps = ps * z + -1.98412698298579493134e-04;
-    ps = ps * z + 8.33333333332248946124e-03;
-    ps = ps * z + -1.66666666666666324348e-01;
-    const double sn = r + r * z * ps;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(r * z, ps, r);
     double pc = -1.13596475577881948265e-11;
-    pc = pc * z + 2.08757232129817482790e-09;
-    pc = pc * z + -2.75573143513906633035e-07;
-    pc = pc * z + 2.48015872894767294178e-05;
-    pc = pc * z + -1.38888888888741095749e-03;
-    pc = pc * z + 4.16666666666666019037e-02;
-    const double cs = 1.0 - 0.5 * z + z * z * pc;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     const int q = (int)((long long)fk & 3);
     const bool swap = (q & 1) != 0;
     double ss = swap ? cs : sn;

@@ -38,8 +38,8 @@
 #define MATH_POLY 1 /* documented polynomials (DESIGN.md "detmath"), bitwise = device */
 
 /* ------------------------------------------------------------------------------
- * detmath: polynomial exp/log/sincos/pow/tanh written ONLY with IEEE + - * / (no fma, no
- * libm) so that a CPU and a GPU evaluation agree bit-for-bit.  Specification in
+ * detmath: polynomial exp/log/sincos/pow/tanh written ONLY with IEEE + - * / and explicit fma (no
+ * libm, no compiler contraction) so that a CPU and a GPU evaluation agree bit-for-bit.  Specification in
  * DESIGN.md section "Deterministic math".  Coefficients are the classic Cephes
  * single-precision / fdlibm double-precision minimax sets.
  * ---------------------------------------------------------------------------- */
@@ -48,17 +48,17 @@ static float det_expf(float x)
     if (x != x) return x;
     if (x > 88.72283f) return INFINITY;
     if (x < -103.0f) return 0.0f;
-    float fk = floorf(x * 1.44269504088896341f + 0.5f);
-    float r = x - fk * 0.693359375f;
-    r = r - fk * -2.12194440e-4f;
+    float fk = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(-fk, 0.693359375f, x);
+    r = fmaf(-fk, -2.12194440e-4f, r);
     float z = r * r;
     float p = 1.9875691500e-4f;
-    p = p * r + 1.3981999507e-3f;
-    p = p * r + 8.3334519073e-3f;
-    p = p * r + 4.1665795894e-2f;
-    p = p * r + 1.6666665459e-1f;
-    p = p * r + 5.0000001201e-1f;
-    p = p * z + r;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
     p = p + 1.0f;
     int k = (int)fk;
     /* scale by 2^k in two exact steps so that subnormal results round once */
@@ -99,24 +99,24 @@ static float det_logf(float x)
 /* double sin/cos for moderate |x| (joint angles, |x| <= ~1e3): Cody-Waite + fdlibm kernels */
 static void det_sincos(double x, double *s, double *c)
 {
-    double fk = floor(x * 0.63661977236758134308 + 0.5);
-    double r = x - fk * 1.57079632673412561417e+00;
-    r = r - fk * 6.07710050650619224932e-11;
+    double fk = floor(fma(x, 0.63661977236758134308, 0.5));
+    double r = fma(-fk, 1.57079632673412561417e+00, x);
+    r = fma(-fk, 6.07710050650619224932e-11, r);
     double z = r * r;
     double ps = 1.58969099521155010221e-10;
-    ps = ps * z + -2.50507602534068634195e-08;
-    ps = ps * z + 2.75573137070700676789e-06;
-    ps = ps * z + -1.98412698298579493134e-04;
-    ps = ps * z + 8.33333333332248946124e-03;
-    ps = ps * z + -1.66666666666666324348e-01;
-    double sn = r + r * z * ps;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    double sn = fma(r * z, ps, r);
     double pc = -1.13596475577881948265e-11;
-    pc = pc * z + 2.08757232129817482790e-09;
-    pc = pc * z + -2.75573143513906633035e-07;
-    pc = pc * z + 2.48015872894767294178e-05;
-    pc = pc * z + -1.38888888888741095749e-03;
-    pc = pc * z + 4.16666666666666019037e-02;
-    double cs = 1.0 - 0.5 * z + z * z * pc;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
     long long q = (long long)fk;
     switch ((int)(q & 3)) {
     case 0: *s = sn;  *c = cs;  break;
