@@ -78,8 +78,10 @@ struct ChemicalReactor {
     }
     __device__ static void step_noise_eval(const ProbitFetch (&f)[KS], double (&n)[KS])
     {
-        n[0] = 0.0 + 0.1 * (double)probit_eval(f[0]);        // temp_noise_std / 10, :149
-        n[1] = 0.0 + 500.0 * (double)probit_eval(f[1]);      // pressure_noise_std / 10, :159
+        // fast-mode step noise is a float32 product (sd * z), handed on as the double the dynamics' noise
+        // argument is (parity mode injects the reference's fp64 draws there): one VALU instead of four fp64 ones
+        n[0] = (double)(0.1f * probit_eval(f[0]));           // temp_noise_std / 10, :149
+        n[1] = (double)(500.0f * probit_eval(f[1]));         // pressure_noise_std / 10, :159
     }
     __device__ static void step_noise(uint32_t w0, uint32_t w1, const float4 *tab, double (&n)[KS])
     {
@@ -221,11 +223,11 @@ struct PowerGrid {
         gen_normals<KS>(k, STREAM_STEP, z);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            n[i] = 0.0 + 0.005 * (double)z[i];                           // :136
-            n[8 + i] = 0.0 + 1.0 * (double)z[8 + i];                     // :140
+            n[i] = (double)(0.005f * z[i]);                              // :136 (float32 product, see ChemicalReactor)
+            n[8 + i] = (double)z[8 + i];                                 // :140 (sd 1.0)
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) n[16 + i] = 0.0 + 2.0 * (double)z[16 + i];   // :144
+        for (int i = 0; i < 7; ++i) n[16 + i] = (double)(2.0f * z[16 + i]);      // :144
     }
 
     // module-level check functions :10-30 (pre-state, clipped action)
@@ -510,8 +512,8 @@ struct SpecPlant {
         constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
         float z[KS];
         gen_normals<KS>(k, STREAM_STEP, z);
-        n[0] = 0.0 + (double)P.nsd[0] * (double)z[0];
-        n[1] = 0.0 + (double)P.nsd[1] * (double)z[1];
+        n[0] = (double)(P.nsd[0] * z[0]);
+        n[1] = (double)(P.nsd[1] * z[1]);
     }
 
     // box constraint c: every row of [cfirst, cfirst + ccount) inside [clo, chi]; bit set = violated

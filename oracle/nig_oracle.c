@@ -896,7 +896,7 @@ static void gen_uniforms(uint64_t seed, uint64_t env_index, uint32_t t, uint32_t
     }
 }
 
-/* step noise in the reference's draw order and scaling (loc + scale * z, fp64) */
+/* step noise in the reference's draw order; fast-mode value = float32 product sd * z, widened to double */
 void oracle_gen_step_noise(int env, uint64_t seed, uint64_t env_index, uint32_t t, double *noise)
 {
     float z[24];
@@ -905,18 +905,18 @@ void oracle_gen_step_noise(int env, uint64_t seed, uint64_t env_index, uint32_t 
          * words 0-1 for the odd counter, 2-3 for the even one */
         gen_normals(seed, env_index, (t + 1u) >> 1, STREAM_STEP, 4, z);
         const float *zz = z + 2 * (1u - (t & 1u));
-        noise[0] = 0.0 + 0.1 * (double)zz[0];
-        noise[1] = 0.0 + 500.0 * (double)zz[1];
+        noise[0] = (double)(0.1f * zz[0]);                      /* fast-mode step noise: float32 product sd * z */
+        noise[1] = (double)(500.0f * zz[1]);
     } else if (env == ORACLE_PG) {                             /* power_grid.py:136,140,144 */
         gen_normals(seed, env_index, t, STREAM_STEP, 23, z);
-        for (int i = 0; i < 8; i++) noise[i] = 0.0 + 0.005 * (double)z[i];
-        for (int i = 0; i < 8; i++) noise[8 + i] = 0.0 + 1.0 * (double)z[8 + i];
-        for (int i = 0; i < 7; i++) noise[16 + i] = 0.0 + 2.0 * (double)z[16 + i];
+        for (int i = 0; i < 8; i++) noise[i] = (double)(0.005f * z[i]);
+        for (int i = 0; i < 8; i++) noise[8 + i] = (double)z[8 + i];
+        for (int i = 0; i < 7; i++) noise[16 + i] = (double)(2.0f * z[16 + i]);
     } else if (env >= ORACLE_SPEC0) {
         const spec_plant_t *P = &SPEC_PLANTS[env - ORACLE_SPEC0];
         gen_normals(seed, env_index, t, STREAM_STEP, 2, z);
-        noise[0] = 0.0 + (double)P->nsd[0] * (double)z[0];
-        noise[1] = 0.0 + (double)P->nsd[1] * (double)z[1];
+        noise[0] = (double)(P->nsd[0] * z[0]);
+        noise[1] = (double)(P->nsd[1] * z[1]);
     }
 }
 
