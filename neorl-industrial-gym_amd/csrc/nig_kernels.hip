@@ -426,9 +426,9 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
     const bool in_range = base + tid < p.B;
-    if constexpr (!COMPACT && OUT != 3) {
-        if (!in_range) return;       // compacting blocks keep every thread for the barriers, row-major
-    }                                // output keeps them to move the rows of a partial wave's live lanes
+    if constexpr (!COMPACT) {
+        if (!in_range) return;       // compacting blocks keep every thread for the barriers.  (From here on the
+    }                                // compiler knows in_range: no exec masking around the loop's loads and stores.)
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
     const uint64_t gi = p.env0 + (uint64_t)(base + tid);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
@@ -560,14 +560,15 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
                     if (16 * S % 64 == 0 || lane + 64u * k < 16u * S) stream_store(oo + lane + 64u * k, v[k]);
-            } else if constexpr (S % 4 == 0) {
+            } else if (in_range) {                 // the batch's last, partial wave (its other lanes may have exited):
+                float *row = obs_row + (size_t)lane * S;       // every live lane writes its own row
+                if constexpr (S % 4 == 0) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k)
-                    if (wave_env0 + (lane + 64u * k) / (unsigned)(S / 4) < p.B) stream_store(oo + lane + 64u * k, v[k]);
-            } else if (in_range) {                 // partial wave, rows not float4-sized: the lane's own row, dword by dword
-                float *row = obs_row + (size_t)lane * S;
+                    for (int k = 0; k < S / 4; ++k) store16(row + 4 * k, n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]);
+                } else {
 #pragma unroll
-                for (int k = 0; k < S; ++k) row[k] = n[k];
+                    for (int k = 0; k < S; ++k) row[k] = n[k];
+                }
             }
         }
         if (in_range) {
