@@ -236,8 +236,9 @@ int nig_plan_destroy(nig_plan *p);
  *                (0 = overwrite)
  *   obs_out      optional (needs reward_out/flags_out) float trajectory: observation returned by step k (the terminal one for
  *                a lane that finishes) at obs_out + k*obs_step_stride, laid out [S][ld_obs], or
- *                -- with ld_obs == 0 -- row-major [B][S] (16-byte aligned; the D4RL
- *                observations[N,S] layout, written with 16-byte stores)
+ *                -- with ld_obs == 0 -- row-major [B][S] (the D4RL observations[N,S] layout; obs_out
+ *                16-byte aligned and obs_step_stride a multiple of 4 floats, i.e. B*S % 4 == 0 for a
+ *                dense trajectory: each wave's 64 rows leave as whole-line 16-byte streaming stores)
  * Stands in for the step loops of the reference's harnesses: benchmark_environment_steps
  * (performance_benchmark.py:106-133) and the get_dataset episode loops
  * (chemical_reactor.py:364-405, power_grid.py:209-237, robot_assembly.py:259-296).
