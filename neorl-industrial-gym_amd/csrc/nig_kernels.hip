@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 // ------------------------------------------------------------------------------------------
 // Closed-loop fused rollout: action = on-device policy(observation) -> IndustrialEnv.step, n steps
 // per launch, state / counters / tallies / PID memory in registers.  No loads inside the loop
-// (the policy struct is read through the scalar cache), so the optional outputs can stay
+// (the policy struct is staged in LDS), so the optional outputs can stay
 // run-time switches.  Spec of the policy arithmetic: include/nig.h "nig-policy-v1".
 struct PolicyArgs {
     StepArgs s;
@@ -774,7 +774,17 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
-    NIG_STAGE_PROBIT(s_probit);
+    // The policy struct is staged in LDS: read from global memory inside the loop, every field was a
+    // vector load followed by a full vmcnt(0) (the loop's stores may alias it, so hipcc neither hoists
+    // the loads nor uses the scalar cache) -- ~20 serialised L2 round trips per step, 60 % of the step.
+    __shared__ nig_policy s_pol;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&s_pol);
+        for (unsigned i = threadIdx.x; i < sizeof(nig_policy) / 4; i += BLOCK) dst[i] = src[i];
+    }
+    NIG_STAGE_PROBIT(s_probit);                    // (ends with the block barrier that also publishes s_pol)
+    const nig_policy *pol = &s_pol;
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
@@ -803,7 +813,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
             continue;
         }
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
-        policy_action<Env>(q.pol, s, key, integ, eprev, a);
+        policy_action<Env>(pol, s, key, integ, eprev, a);
         if (q.obs_out) {
             float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + tid) * S;
             if constexpr (S % 4 == 0) {

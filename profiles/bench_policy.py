@@ -50,4 +50,17 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 env.rollout_policy(T)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 out["affine_fused"] = {"env_steps_per_s": B * T / dt, "us_per_step": dt / T * 1e6}
+# the same closed loop writing the D4RL transition stream (observation, action, reward, flag word per step)
+Tf = min(T, 100)
+obs = torch.empty(Tf, B, S, dtype=torch.float32, device=env.device)
+act = torch.empty(Tf, A, env.ld, dtype=torch.float32, device=env.device)
+rew = torch.empty(Tf, env.ld, dtype=torch.float32, device=env.device)
+fl = torch.empty(Tf, env.ld, dtype=torch.int32, device=env.device)
+env.rollout_policy(Tf, rew, fl, obs, act)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(4):
+    env.rollout_policy(Tf, rew, fl, obs, act)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+out["affine_fused_transitions"] = {"env_steps_per_s": 4 * B * Tf / dt, "us_per_step": dt / (4 * Tf) * 1e6,
+                                   "GBps_written": 4 * B * Tf * (4 * S + 4 * A + 8) / dt / 1e9}
 print(json.dumps(out))
