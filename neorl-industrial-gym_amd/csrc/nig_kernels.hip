@@ -289,8 +289,17 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
             for (int k = 0; k < KS; ++k) nz[k] = 0.0;
         }
     }
-    // stage the generator's table only now: the state/action loads above are already in flight
-    NIG_STAGE_PROBIT(s_probit);
+    // The generator's table: staged in LDS (only now: the state/action loads above are already in flight)
+    // when a lane looks up many normals per launch; an env with a couple of draws per step reads its
+    // entries straight from the 12 KiB global table (L2-resident) -- staging 12 KiB per block plus a
+    // block barrier costs more than two or three 16-byte loads per lane.
+    constexpr bool STAGE_TABLE = PARITY ? false : (KS > 4);
+    __shared__ float4 s_probit_[STAGE_TABLE ? 768 : 1];
+    if constexpr (STAGE_TABLE) {
+        for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
+        __syncthreads();
+    }
+    const float4 *s_probit = STAGE_TABLE ? s_probit_ : NIG_PROBIT;
     const bool active = in_range && !(ctr & NIG_CTR_DONE);     // base.py:159-160: finished lanes wait for reset
 
     const RngKey key = make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, s_probit);
