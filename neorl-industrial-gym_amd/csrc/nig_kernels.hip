@@ -787,6 +787,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     // vector load followed by a full vmcnt(0) (the loop's stores may alias it, so hipcc neither hoists
     // the loads nor uses the scalar cache) -- ~20 serialised L2 round trips per step, 60 % of the step.
     __shared__ nig_policy s_pol;
+    __shared__ v4f s_tr[BLOCK / 64][16 * S];       // per-wave transpose of the row-major observation rows
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s_pol);
@@ -824,19 +825,42 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         policy_action<Env>(pol, s, key, integ, eprev, a);
         if (q.obs_out) {
-            float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + tid) * S;
-            if constexpr (S % 4 == 0) {
+            // Row-major observations.  When every lane of the wave is live (exists, not frozen) the 64 rows
+            // leave through the wave-private LDS image as whole-line streaming stores, as in rollout_kernel;
+            // a wave with frozen lanes (their rows stay untouched) or the partial last wave writes row by row.
+            // (Only for batches that put several waves on a SIMD: at one wave per SIMD the kernel is
+            // issue-bound and the extra LDS round trip costs 5 %, above that it is worth +22 %.)
+            if (p.B > 2u * 65536u && __ballot(true) == ~0ull) {
+                const unsigned lane = tid & 63u;
+                v4f *tr = s_tr[tid >> 6];
+                if constexpr (S % 4 == 0) {
 #pragma unroll
-                for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
-            } else {                               // rows that are not a multiple of 16 bytes: dword stores
+                    for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; tr[lane * (S / 4) + k] = v; }
+                } else {
+                    float *trf = reinterpret_cast<float *>(tr) + lane * S;
 #pragma unroll
-                for (int k = 0; k < S; ++k) oo[k] = s[k];
+                    for (int k = 0; k < S; ++k) trf[k] = s[k];
+                }
+                v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S);
+                constexpr int NV = (16 * S + 63) / 64;
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (16 * S % 64 == 0 || lane + 64u * k < 16u * S) stream_store(oo + lane + 64u * k, tr[lane + 64u * k]);
+            } else {
+                float *oo = q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + tid) * S;
+                if constexpr (S % 4 == 0) {
+#pragma unroll
+                    for (int k = 0; k < S / 4; ++k) store16(oo + 4 * k, s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+                } else {                           // rows that are not a multiple of 16 bytes: dword stores
+#pragma unroll
+                    for (int k = 0; k < S; ++k) oo[k] = s[k];
+                }
             }
         }
         if (q.act_out) {
             float *ao = q.act_out + (size_t)it * q.act_step_stride + base;
 #pragma unroll
-            for (int j = 0; j < A; ++j) (ao + j * q.ld_act_out)[tid] = a[j];
+            for (int j = 0; j < A; ++j) stream_store(ao + j * q.ld_act_out + tid, a[j]);
         }
         if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
@@ -851,8 +875,8 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
             if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
             else ret = ret + (double)res.reward;
         }
-        if (p.reward) (p.reward + base + orow)[tid] = (float)res.reward;
-        if (p.flags) (p.flags + base + orow)[tid] = fl;
+        if (p.reward) stream_store(p.reward + base + orow + tid, (float)res.reward);
+        if (p.flags) stream_store(p.flags + base + orow + tid, fl);
         if (done) {
             lt.life += (long long)viol_ep;
             if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
