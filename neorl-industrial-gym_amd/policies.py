@@ -106,11 +106,20 @@ def random_agent(state_dim: int, action_dim: int, action_low: float = -1.0, acti
 
 
 # (episodes, step cap) of each get_dataset quality
+from .spec_plants import PLANTS as _PLANT_LIST  # noqa: E402
+
+_SPEC_PLANTS = {p["name"]: p for p in _PLANT_LIST}
+for _p in _PLANT_LIST:
+    _DIMS[_p["name"]] = (len(_p["y"]) + len(_p["act"]) + 3, len(_p["act"]))
+
 DATASET_SHAPE = {
     "ChemicalReactor-v0": {"expert": (100, 400), "medium": (200, 350), "mixed": (300, 300), "random": (500, 200)},
     "PowerGrid-v0": {"expert": (100, 1000), "medium": (150, 1000), "mixed": (200, 1000), "random": (80, 1000)},
     "RobotAssembly-v0": {"expert": (120, 1000), "medium": (180, 1000), "mixed": (250, 1000), "random": (100, 1000)},
 }
+# README-only envs: (episodes, step cap) chosen here, nothing upstream to follow
+for _p in _PLANT_LIST:
+    DATASET_SHAPE[_p["name"]] = {"expert": (100, 500), "medium": (150, 500), "mixed": (200, 500), "random": (100, 500)}
 
 
 def behaviour_policy(env_id: str, quality: str) -> DevicePolicy:
@@ -152,7 +161,35 @@ def behaviour_policy(env_id: str, quality: str) -> DevicePolicy:
             W[j, j], b[j] = -1.0, tgt[j]
         return DevicePolicy(S, A, W=W, b=b, half_range=[0, 0, 0, 0.5, 0.5, 0.5, 0.5], p_uniform=0.3,
                             uniform_range=0.8, clip=(-2.0, 2.0))
+    if env_id in _SPEC_PLANTS:                               # build-specified plants: proportional control on the table
+        return _spec_behaviour(_SPEC_PLANTS[env_id], quality)
     raise ValueError(env_id)
+
+
+def _spec_behaviour(P, quality: str) -> DevicePolicy:
+    """Data-collection policies of the four README-only envs (no upstream get_dataset exists for them):
+    a proportional controller read off the plant table -- actuator j is driven against the weighted
+    setpoint errors of the variables it acts on, u_j = -kp * sum_i w_i sign(G_ij) (y_i - sp_i) / span_i --
+    plus Gaussian exploration noise (expert), a weaker gain with an epsilon-uniform mixture (medium,
+    mixed), or uniform actions (random)."""
+    ys, acts = P["y"], P["act"]
+    NP_, A = len(ys), len(acts)
+    S = NP_ + A + 3
+    if quality == "random":
+        return DevicePolicy(S, A, p_uniform=1.0, uniform_range=1.0, clip=(-1.0, 1.0))
+    kp, sigma, eps = {"expert": (2.0, 0.05, 0.0), "medium": (1.0, 0.15, 0.1)}.get(quality, (0.5, 0.3, 0.3))
+    W = np.zeros((A, S))
+    b = np.zeros(A)
+    aidx = {a["name"]: j for j, a in enumerate(acts)}
+    for i, y in enumerate(ys):
+        if y["w"] == 0.0:
+            continue
+        span = max(abs(y["hi"] - y["lo"]), 1e-6)
+        for name, g in y["gains"].items():
+            c = -kp * np.sign(g) * min(1.0, y["w"] * 10.0) / span * 10.0
+            W[aidx[name], i] += c
+            b[aidx[name]] -= c * y["sp"]
+    return DevicePolicy(S, A, W=W, b=b, sigma=[sigma] * A, p_uniform=eps, uniform_range=1.0, clip=(-1.0, 1.0))
 
 
 class MLPPolicy:

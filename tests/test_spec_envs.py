@@ -242,3 +242,20 @@ def test_seven_env_mixed_batch(ni):
         assert torch.equal(e.get_state().view(torch.int32), alone.get_state().view(torch.int32)), e.env_id
         alone.close()
     mix.close()
+
+
+@gpu
+@pytest.mark.parametrize("key", list(SPEC))
+def test_get_dataset_for_spec_envs(ni, key):
+    """get_dataset works for the build-specified envs too (behaviour policy = proportional control read off the
+    plant table); the expert set is better than the random one."""
+    name, S, A = SPEC[key]
+    env = ni.make_batched(name, 256, autoreset=False, tally=True)
+    d = {q: env.get_dataset(q) for q in ("expert", "random")}
+    for q, ds in d.items():
+        n = ds["observations"].shape[0]
+        assert ds["observations"].shape == (n, S) and ds["actions"].shape == (n, A)
+        assert ds["rewards"].shape == (n,) and ds["terminals"].shape == (n,) and n > 1000
+        assert float(ds["actions"].abs().max()) <= 1.0
+    assert float(d["expert"]["rewards"].mean()) > float(d["random"]["rewards"].mean())
+    env.close()
