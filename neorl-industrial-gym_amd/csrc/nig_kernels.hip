@@ -117,11 +117,13 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
 template <class Env>
 __device__ __forceinline__ uint32_t pack_flags(const StepResult<Env> &res, int step)
 {
-    return (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
-           ((res.viol_bits & 7u) << NIG_FLAG_VIOL_SHIFT) | ((res.viol_bits & 8u) ? NIG_FLAG_VIOL3 : 0u) |
-           (((uint32_t)res.nviol & 3u) << NIG_FLAG_NVIOL_SHIFT) | (((uint32_t)res.nviol & 4u) ? NIG_FLAG_NVIOL_HI : 0u) |
-           ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.shutdown ? NIG_FLAG_SHUTDOWN : 0u) |
-           ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
+    uint32_t f = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
+                 ((res.viol_bits & 7u) << NIG_FLAG_VIOL_SHIFT) | (((uint32_t)res.nviol & 3u) << NIG_FLAG_NVIOL_SHIFT) |
+                 ((uint32_t)res.ncrit << NIG_FLAG_NCRIT_SHIFT) | (res.shutdown ? NIG_FLAG_SHUTDOWN : 0u) |
+                 ((uint32_t)step << NIG_FLAG_STEP_SHIFT);
+    if constexpr (Env::CUSTOM_STEP)                // only the Advanced envs carry a 4th condition / a count of 4
+        f |= ((res.viol_bits & 8u) ? NIG_FLAG_VIOL3 : 0u) | (((uint32_t)res.nviol & 4u) ? NIG_FLAG_NVIOL_HI : 0u);
+    return f;
 }
 
 // Per-lane key of the counter-based generator: (global env index, launch counter t).
@@ -447,7 +449,10 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     float s[S], a[A], n[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld_state)[tid] : 0.0f;
-    double ret = (tally && in_range) ? (p.ep_ret + base)[tid] : 0.0;
+    // running episode return in the precision the reference accumulates it in (float32 for ChemicalReactor:
+    // the stored double is exactly that float), widened only when an episode ends
+    using ret_t = std::conditional_t<Env::RET_F32, float, double>;
+    ret_t ret = (tally && in_range) ? (ret_t)(p.ep_ret + base)[tid] : (ret_t)0;
     LaneTally lt;
     lt.clear();
     // Actions are prefetched TWO steps ahead into two ping-pong register sets (the loop is unrolled
@@ -511,8 +516,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         if (!frozen) {
             ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
             if (tally) {
-                if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
-                else ret = ret + (double)res.reward;
+                ret = ret + (ret_t)res.reward;
             }
         }
         // Next step's process noise, first half: (second step of a pair) the Philox rounds of the next
@@ -601,7 +605,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         }
         if (done) {
             lt.life += (long long)viol_ep;
-            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (tally) { lt.episode((double)ret, step, viol_ep, res.ncrit); ret = (ret_t)0; }
             if (!autoreset) ctr |= NIG_CTR_DONE;
         }
         if constexpr (!COMPACT) {
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     (p.ctr + base)[tid] = ctr;
     if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
     if (tally) {
-        (p.ep_ret + base)[tid] = ret;
+        (p.ep_ret + base)[tid] = (double)ret;
         if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld);
     }
 }
