@@ -259,3 +259,27 @@ def test_get_dataset_for_spec_envs(ni, key):
         assert float(ds["actions"].abs().max()) <= 1.0
     assert float(d["expert"]["rewards"].mean()) > float(d["random"]["rewards"].mean())
     env.close()
+
+
+@gpu
+@pytest.mark.parametrize("key", list(SPEC))
+def test_evaluate_with_safety_on_spec_envs(ni, key):
+    """evaluate_with_safety (utils.py:42-154 surface) on the build-specified envs: batched on the device, and the
+    single-env host loop; a do-nothing agent beats a random one (the plants rest at their operating point)."""
+    name, S, A = SPEC[key]
+    keys13 = None
+    res = {}
+    for tag, agent in (("hold", ni.constant_agent(S, A)), ("random", ni.random_agent(S, A))):
+        env = ni.make_batched(name, 128, tally=True, autoreset=False, max_episode_steps=200)
+        res[tag] = ni.evaluate_with_safety(agent, env, n_episodes=128)
+        keys13 = keys13 or set(res[tag])
+        assert set(res[tag]) == keys13 and len(keys13) == 13
+        assert all(np.isfinite(v) for v in res[tag].values() if isinstance(v, (int, float)))
+        env.close()
+    assert res["hold"]["return_mean"] > res["random"]["return_mean"]
+    assert res["hold"]["safety_violations"] <= res["random"]["safety_violations"]
+    np.random.seed(3)
+    single = ni.make(name, max_episode_steps=30)
+    out = ni.evaluate_with_safety(ni.constant_agent(S, A), single, n_episodes=2)
+    assert set(out) == keys13 and out["length_mean"] == 30.0
+    single.close()
