@@ -1786,6 +1786,8 @@ static HostStage host_stage_layout(const nig_handle *h)
     return L;
 }
 
+constexpr int64_t HOST_ZERO_COPY_MAX = 1024;   // lanes up to which the host-buffer entry points skip the staging copies
+
 static int host_stage_ensure(nig_handle *h, const HostStage &L)
 {
     if (h->hst_pinned && h->hst_bytes >= L.bytes) return NIG_OK;
@@ -1842,14 +1844,21 @@ int nig_step_host(nig_handle *h, const float *actions, const double *step_noise,
         up = L.off_noise + (size_t)sp.k_step * B * 8;          // one contiguous upload covers both
         dn = (const double *)(h->hst_dev + L.off_noise);
     }
-    HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
-    rc = nig_step(h, (const float *)(h->hst_dev + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
-                  (double *)(h->hst_dev + L.off_rew), (uint32_t *)(h->hst_dev + L.off_flags), nullptr, 0, stream);
+    // Small batches (the single-env drop-in class is B = 1): the kernels read the actions / noise from, and
+    // write state / reward / flags to, the pinned staging buffer itself -- hipHostMalloc memory is mapped
+    // and coherent, a few hundred bytes over PCIe cost less than two copy commands -- so a step is two
+    // kernel launches and one stream sync.  Larger batches keep one upload + one download.
+    const bool zero_copy = h->B <= HOST_ZERO_COPY_MAX;
+    char *io = zero_copy ? h->hst_pinned : h->hst_dev;
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
+    if (dn) dn = (const double *)(io + L.off_noise);
+    rc = nig_step(h, (const float *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
+                  (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream);
     if (rc != NIG_OK) return rc;
     // state rows gathered next to reward64 and flags: one download for everything the call returns
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
-                       (float *)(h->hst_dev + L.off_state), (int64_t)B, sp.state_dim, h->B);
-    HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, L.bytes - L.off_state, hipMemcpyDeviceToHost, st));
+                       (float *)(io + L.off_state), (int64_t)B, sp.state_dim, h->B);
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, L.bytes - L.off_state, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);
     memcpy(reward64_out, h->hst_pinned + L.off_rew, B * 8);
