@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--outputs", default="full", choices=["full", "min", "none"],
                     help="rollout mode: full = obs trajectory + reward + flags per step; min = reward + flags; none")
     ap.add_argument("--traj", default="aos", choices=["aos", "soa"], help="observation trajectory layout: [T,B,S] or [T,S,ld]")
+    ap.add_argument("--mixed-set", default="readme", choices=["readme", "survey"],
+                    help="--env mixed: the README's seven envs, or SURVEY 8(d).4's seven (the three reference envs + the two "
+                         "Advanced candidates + two README-only plants)")
     ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
     ap.add_argument("--calibrate", action="store_true", help="also run known-size dword copies (PMC calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -307,6 +310,13 @@ MIXED7 = [("ChemicalReactor-v0", 12, 3, "reference"), ("RobotAssembly-v0", 24, 7
           ("SupplyChain-v0", 28, 10, "build-specified")]
 
 
+MIXED7_SURVEY = [("ChemicalReactor-v0", 12, 3, "reference"), ("PowerGrid-v0", 32, 8, "reference"),
+                 ("RobotAssembly-v0", 24, 7, "reference"),
+                 ("AdvancedChemicalReactor-v0", 20, 6, "restated from source text (not instantiable upstream)"),
+                 ("AdvancedPowerGrid-v0", 32, 8, "restated from source text (not instantiable upstream)"),
+                 ("HVACControl-v0", 18, 5, "build-specified"), ("WaterTreatment-v0", 15, 4, "build-specified")]
+
+
 def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     """BASELINE config 4: the README's seven environments (README.md:24-32) in ONE padded SoA batch of
     --batch lanes (default 1 048 576), contiguous 256-aligned segments of equal size, one rollout
@@ -316,9 +326,10 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     with reward+flags outputs."""
     B = args.batch or 1048576
     per = (B // 7) // 256 * 256
-    counts = [(name, per if i else B - 6 * per) for i, (name, _, _, _) in enumerate(MIXED7)]
-    dims = {name: (S, A) for name, S, A, _ in MIXED7}
-    origin = {name: o for name, _, _, o in MIXED7}
+    envset = MIXED7 if args.mixed_set == "readme" else MIXED7_SURVEY
+    counts = [(name, per if i else B - 6 * per) for i, (name, _, _, _) in enumerate(envset)]
+    dims = {name: (S, A) for name, S, A, _ in envset}
+    origin = {name: o for name, _, _, o in envset}
     mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B)
     R, P = min(args.ring, 16), max(1, min(args.plan_steps, args.steps))
     ring = torch.zeros(R, mix.A_max, mix.ld, dtype=torch.float32, device=device)
