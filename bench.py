@@ -3,23 +3,27 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE).
-A "step" = one IndustrialEnv.step() of every lane of the batch.  Workload at N=1 =
-BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs, uniform random float32
-actions from a pre-filled on-device ring, process noise and auto-reset drawn in-kernel from the
-counter-based generator (synthetic data).  Every rank runs the same per-GPU batch
-(weak scaling); lanes are keyed by global index; the only collective is the all-gather of the
-11-double episode tally after the timed region.
+
+One bench "step" = ONE PASS of the hot path over the batch = one fused launch that runs
+--plan-steps (default 250) consecutive IndustrialEnv.step() calls of every lane (the shape of
+the reference's own measurement loop, performance_benchmark.py:106-133: act -> step -> reset on
+done).  K timed launches, W untimed; `ms_per_step` is per launch; `config.env_steps_per_step`
+= plan_steps x batch; `value` = K x plan_steps x batch x N / wall.
+
+Workload at N=1 = BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs, uniform
+random float32 actions from a pre-filled on-device ring, process noise and auto-reset drawn
+in-kernel from the counter-based generator (synthetic data).  Every rank runs the same
+per-GPU batch (weak scaling); lanes are keyed by global index; the only collective is the
+all-gather of the episode tally after the timed region.
 
 Modes (same arithmetic, bit-identical results -- tests/test_gpu_parity.py):
-  rollout (default)  fused rollout kernel: --plan-steps env.step per launch, state in registers;
-                     EVERY step's return values are still materialised in HBM (observation
-                     trajectory, reward, flag word), i.e. the information of the step API.
+  rollout (default)  fused rollout kernel, state in registers; EVERY env.step's return values are
+                     still materialised in HBM (observation trajectory, reward, flag word).
   graph / eager      step API: one step-kernel launch per env.step (state round-trips HBM),
-                     replayed from a hipGraph / launched one by one.
-The headline `value` is the selected mode; the default run also times the step API for a
-shorter stretch and reports it under "step_api".
+                     --plan-steps of them replayed from one hipGraph / launched one by one.
 
-One JSON line on rank 0:  metric/value/unit/... + "roofline" + "cpu_baseline" (+ "parity").
+One JSON line on rank 0: metric/value/... + "roofline" + "cpu_baseline" (+ "parity", "step_api",
+"powergrid" = BASELINE configs[2] per GPU, i.e. configs[4] when N = 8).
 """
 import argparse
 import json
@@ -31,8 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS = {"cr": "ChemicalReactor-v0", "pg": "PowerGrid-v0", "ra": "RobotAssembly-v0"}
-DIMS = {"cr": (12, 3), "pg": (32, 8), "ra": (24, 7)}
+KERNEL_ENV = {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}
+BASELINE_BATCH = {"cr": 65536, "pg": 262144, "ra": 262144}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+REFERENCE_PYTHON_1CORE = 21409  # reference NumPy path, ChemicalReactor-v0, 1 core, build container
 
 
 def alg_bytes_per_step(S, A):
@@ -48,11 +54,200 @@ def alg_bytes_rollout(S, A, outputs):
     return 4 * A + {"full": 4 * S + 8, "min": 8, "none": 0}[outputs]
 
 
+def measured_traffic(key, B, mode, outputs, P):
+    """HBM bytes per env-step from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE,
+    separate passes, calibrated).  Only returned when the profiled launch had the same number of
+    env.step per launch as this run (the per-launch prologue/epilogue is amortised over it)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(tpath)).get(f"{key}_{B}_{mode}_{outputs if mode == 'rollout' else 'step'}")
+    except Exception:
+        return None, None
+    if not rec or int(rec.get("plan_steps", -1)) != int(P):
+        return None, None
+    return float(rec["hbm_bytes_per_env_step"]), rec.get("source")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Workload:
+    """One env type on this rank's GPU with its action ring and output buffers resident in HBM."""
+
+    def __init__(self, ni, torch, key, B, device, rank, mode, P, ring_len, outputs, traj_layout, seed=0x5EED):
+        self.ni, self.torch, self.key, self.B, self.mode, self.P = ni, torch, key, B, mode, P
+        self.outputs = outputs
+        env = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=rank * B, autoreset=True, tally=True)
+        self.env = env
+        self.S, self.A = env.state_dim, env.action_dim
+        self.R = ring_len
+        self.ring = torch.empty(ring_len, self.A, env.ld, dtype=torch.float32, device=device)
+        for s in range(ring_len):
+            env.fill_actions(1000 + s, self.ring[s])
+        env.reset()
+        self.rew = self.fl = self.traj = None
+        if mode == "rollout" and outputs != "none":
+            self.rew = torch.empty(P, env.ld, dtype=torch.float32, device=device)
+            self.fl = torch.empty(P, env.ld, dtype=torch.int32, device=device)
+            if outputs == "full":
+                self.traj = (torch.empty(P, B, self.S, dtype=torch.float32, device=device) if traj_layout == "aos"   # row-major [T,B,S]
+                             else torch.empty(P, self.S, env.ld, dtype=torch.float32, device=device))
+        self.plan = env.make_plan(P, self.ring, env.reward, env.flags) if mode == "graph" else None
+
+    def launch(self):
+        """One bench step: P env.step of every lane."""
+        if self.mode == "rollout":
+            self.env.rollout(self.P, self.ring, self.rew, self.fl, self.traj)
+        elif self.mode == "graph":
+            self.plan.launch()
+        else:
+            for k in range(self.P):
+                self.env.step_raw(self.ring[k % self.R], self.env.ld, reward=True, flags=True)
+
+    def kernels_per_launch(self):
+        return 1 if self.mode == "rollout" else self.P
+
+    def close(self):
+        if self.plan is not None:
+            self.plan.close()
+        self.env.close()
+
+
+def timed(torch, dist, world, comm_dev, wl, K, W):
+    """W untimed + exactly K timed launches, bracketed by barrier + synchronize on both sides;
+    HIP events on the launch stream around the same region.  Returns (wall s, device ms): max over ranks."""
+    for _ in range(W):
+        wl.launch()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(K):
+        wl.launch()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    tm = torch.tensor([wall, ev0.elapsed_time(ev1)], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    return float(tm[0].item()), float(tm[1].item())
+
+
+def roofline_of(wl, K, dev_ms):
+    rollout = wl.mode == "rollout"
+    bytes_step = alg_bytes_rollout(wl.S, wl.A, wl.outputs) if rollout else alg_bytes_per_step(wl.S, wl.A)
+    n_kernels = K * wl.kernels_per_launch()
+    kernel_us = dev_ms * 1e3 / n_kernels                        # HIP events over the timed region / kernel launches in it
+    env_steps_per_kernel = wl.B * (wl.P if rollout else 1)
+    alg = bytes_step * env_steps_per_kernel
+    achieved = alg / (kernel_us * 1e-6) / 1e9
+    per_step, src = measured_traffic(wl.key, wl.B, wl.mode, wl.outputs, wl.P)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None if per_step is None else per_step * env_steps_per_kernel,
+            "traffic_bytes_per_env_step": per_step, "traffic_source": src,
+            "kernel": ("rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], {"none": 0, "min": 1, "full": 3}[wl.outputs])
+                       if rollout else "step_kernel<%s,false>" % KERNEL_ENV[wl.key]),
+            "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_kernel,
+            "alg_bytes_per_launch": alg, "launch_us": kernel_us, "launches_timed": n_kernels,
+            "bytes_model": ("fused-rollout figure (SURVEY 8d): action read + requested per-step outputs"
+                            if rollout else "step-API figure (SURVEY 8d): 8S+4A+16")}
+
+
+def gathered_tally(torch, dist, world, comm_dev, wl):
+    """The path's one exchange: all-gather of every rank's partial tally + fixed-order combine.
+    Self-check: every rank contributed and the combined counts are the sums of the per-rank ones."""
+    from neorl_industrial_gym_amd.parallel import all_gather_partials, combine_partials
+    L = wl.ni._lib
+    parts = all_gather_partials(wl.env.reduce_tally().to(comm_dev)).cpu()
+    total = combine_partials(parts).numpy()
+    per_rank_eps = [int(x) for x in parts[:, L.T_EPISODES].tolist()]
+    ok = (parts.shape[0] == world and all(e > 0 for e in per_rank_eps)
+          and int(total[L.T_EPISODES]) == sum(per_rank_eps)
+          and int(total[L.T_VIOL]) == sum(int(x) for x in parts[:, L.T_VIOL].tolist()))
+    if not ok:
+        raise SystemExit(f"tally self-check failed: ranks={parts.shape[0]}/{world} episodes per rank={per_rank_eps} "
+                         f"combined={int(total[L.T_EPISODES])}")
+    return total, {"ranks": int(parts.shape[0]), "episodes_per_rank": per_rank_eps, "ok": True}
+
+
+def parity_probe(ni, torch, key, B, device, seed=0x5EED, Tp=256):
+    """The workload's first Tp steps against the CPU oracle, bit for bit (before any timing)."""
+    import numpy as np
+    from oracle import oracle as O
+    L0 = ni._lib
+    penv = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=0, autoreset=True)
+    A = penv.action_dim
+    pring = torch.empty(Tp, A, penv.ld, dtype=torch.float32, device=device)
+    for t in range(Tp):
+        penv.fill_actions(t + 1, pring[t])         # slot k = the generator's action stream at t = k + 1
+    pfl = torch.zeros(Tp, penv.ld, dtype=torch.int32, device=device)
+    prw = torch.zeros(Tp, penv.ld, dtype=torch.float32, device=device)
+    penv.reset()
+    penv.rollout(Tp, pring, prw, pfl)
+    viol = ((pfl[:, :B] >> L0.FLAG_NVIOL_SHIFT) & 3).sum()
+    crit = ((pfl[:, :B] >> L0.FLAG_NCRIT_SHIFT) & 3).sum()
+    nres = ((pfl[:, :B] & L0.FLAG_DID_RESET) != 0).sum()
+    st, sc, tot, _ = O.rollout(key, B, Tp, seed=seed, flavor=O.MATH_POLY, nthreads=min(os.cpu_count() or 1, 32))
+    same = bool(np.array_equal(penv.get_state().cpu().numpy().view(np.uint32), st.view(np.uint32)))
+    out = {"lanes": B, "steps": Tp, "violations_gpu": int(viol.item()), "violations_cpu": int(tot.violations),
+           "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical),
+           "episodes_gpu": int(nres.item()), "episodes_cpu": int(tot.episodes), "state_bits_equal": same}
+    penv.close()
+    return out
+
+
+def cpu_baseline(key, B, seconds, seed=0x5EED):
+    """oracle/nig_oracle.c (the parity-checked C restatement, libm math) timed on this host: all cores
+    and one thread, each on a bounded sample of the SAME workload (same lanes, seeds, policy, auto-reset)."""
+    from oracle import oracle as O
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+
+    def sample(nthreads, lanes, budget):
+        c0 = time.perf_counter()
+        O.rollout(key, lanes, 4, seed=seed, flavor=O.MATH_LIBM, nthreads=nthreads)
+        per_step = (time.perf_counter() - c0) / 4
+        Tc = int(max(8, min(2000, budget / max(per_step, 1e-6))))
+        c0 = time.perf_counter()
+        _, _, tot, _ = O.rollout(key, lanes, Tc, seed=seed, flavor=O.MATH_LIBM, nthreads=nthreads)
+        cw = time.perf_counter() - c0
+        return tot.steps / cw, Tc, cw
+
+    v_all, T_all, w_all = sample(cores, B, seconds)
+    lanes1 = min(B, 4096)
+    v_one, T_one, w_one = sample(1, lanes1, min(seconds, 3.0))
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{B} lanes x {T_all} steps of the same workload (oracle/nig_oracle.c, OpenMP over lanes, "
+                      f"libm math), {w_all:.2f} s wall",
+            "threads_1": {"value": v_one, "unit": "env-steps/s",
+                          "sample": f"{lanes1} lanes x {T_one} steps, 1 thread, {w_one:.2f} s wall"},
+            "cpu_model": cpu_model(),
+            "reference_python_1core": {"value": REFERENCE_PYTHON_1CORE, "unit": "env-steps/s",
+                                       "note": "the reference's own NumPy step loop, ChemicalReactor-v0, 1 core, measured "
+                                               "in the build container (SURVEY.md section 6); the reference cannot travel "
+                                               "to the GPU box, so this is a stated constant, not a live measurement"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=200, help="timed launches (one launch = --plan-steps env.step of every lane)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed launches")
     ap.add_argument("--env", default="cr", choices=list(ENVS) + ["mixed"],
                     help="mixed = all env types in one padded SoA batch (BASELINE config 4), rollout mode, min outputs")
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
@@ -67,16 +262,21 @@ def main():
     ap.add_argument("--mixed-set", default="readme", choices=["readme", "survey"],
                     help="--env mixed: the README's seven envs, or SURVEY 8(d).4's seven (the three reference envs + the two "
                          "Advanced candidates + two README-only plants)")
+    ap.add_argument("--mixed-launch", default="fused", choices=["fused", "streams"],
+                    help="--env mixed: one kernel launch over all segments (nig_create_mixed) or one launch per segment on its own stream")
     ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
+    ap.add_argument("--no-powergrid", action="store_true", help="skip the secondary PowerGrid (BASELINE configs[2]/[4]) measurement")
     ap.add_argument("--calibrate", action="store_true", help="also run known-size dword copies (PMC calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the all-core CPU baseline sample")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
+
+    # the package (and with it libnig.so, built here if stale) is loaded BEFORE anything touches the GPU
+    import neorl_industrial_gym_amd as ni
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,207 +298,92 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
     comm_dev = torch.device("cpu") if rehearse else device
 
-    import neorl_industrial_gym_amd as ni
-
     if args.env == "mixed":
         return bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank)
     key = args.env
-    B = args.batch or {"cr": 65536, "pg": 262144, "ra": 262144}[key]
-    seed = 0x5EED
-    env = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=rank * B, autoreset=True, tally=True)
-    S, A = env.state_dim, env.action_dim
+    B = args.batch or BASELINE_BATCH[key]
+    P, K, W = max(1, args.plan_steps), max(1, args.steps), max(0, args.warmup)
 
-    # ---- parity probe (rank 0): the workload's first steps against the CPU oracle, bit for bit
     parity = None
     if rank == 0 and not args.no_parity:
-        from oracle import oracle as O
-        L0 = ni._lib
-        Tp = 256
-        penv = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=0, autoreset=True)
-        pring = torch.empty(Tp, A, penv.ld, dtype=torch.float32, device=device)
-        for t in range(Tp):
-            penv.fill_actions(t + 1, pring[t])         # slot k = the generator's action stream at t = k + 1
-        pfl = torch.zeros(Tp, penv.ld, dtype=torch.int32, device=device)
-        penv.reset()
-        prw = torch.zeros(Tp, penv.ld, dtype=torch.float32, device=device)
-        penv.rollout(Tp, pring, prw, pfl)
-        viol = ((pfl[:, :B] >> L0.FLAG_NVIOL_SHIFT) & 3).sum()
-        crit = ((pfl[:, :B] >> L0.FLAG_NCRIT_SHIFT) & 3).sum()
-        nres = ((pfl[:, :B] & L0.FLAG_DID_RESET) != 0).sum()
-        st, sc, tot, _ = O.rollout(key, B, Tp, seed=seed, flavor=O.MATH_POLY, nthreads=min(os.cpu_count() or 1, 32))
-        same = bool(np.array_equal(penv.get_state().cpu().numpy().view(np.uint32), st.view(np.uint32)))
-        parity = {"lanes": B, "steps": Tp, "violations_gpu": int(viol.item()), "violations_cpu": int(tot.violations),
-                  "critical_gpu": int(crit.item()), "critical_cpu": int(tot.critical),
-                  "episodes_gpu": int(nres.item()), "episodes_cpu": int(tot.episodes), "state_bits_equal": same}
-        del pring, pfl, prw
-        penv.close()
-        del penv
+        parity = parity_probe(ni, torch, key, B, device)
 
-    # ---- workload: action ring resident in HBM before the timed region
-    R = args.ring
-    ring = torch.empty(R, A, env.ld, dtype=torch.float32, device=device)
-    for s in range(R):
-        env.fill_actions(1000 + s, ring[s])
-    env.reset()
-    P = max(1, min(args.plan_steps, args.steps)) if args.mode in ("graph", "rollout") else 1
-    plan = None
-    launches = [0]
-    traj = rew_t = fl_t = None
-    if args.mode == "rollout" and args.outputs != "none":
-        rew_t = torch.empty(P, env.ld, dtype=torch.float32, device=device)
-        fl_t = torch.empty(P, env.ld, dtype=torch.int32, device=device)
-        if args.outputs == "full":
-            traj = (torch.empty(P, B, S, dtype=torch.float32, device=device) if args.traj == "aos"   # row-major [T,B,S]
-                    else torch.empty(P, S, env.ld, dtype=torch.float32, device=device))
-
-    def run_rollout(n):
-        full, rem = divmod(n, P)
-        for _ in range(full):
-            env.rollout(P, ring, rew_t, fl_t, traj)
-        if rem:
-            env.rollout(rem, ring, rew_t, fl_t, traj)
-        launches[0] += full + (1 if rem else 0)
-
-    def run_step_api(n, use_plan):
-        full, rem = (divmod(n, P) if use_plan is not None else (0, n))
-        for _ in range(full):
-            use_plan.launch()
-        for k in range(rem):
-            env.step_raw(ring[k % R], env.ld, reward=True, flags=True)
-        launches[0] += n
-
-    if args.mode == "graph":
-        plan = env.make_plan(P, ring, env.reward, env.flags)
-
-    def run(n):
-        if args.mode == "rollout":
-            run_rollout(n)
-        else:
-            run_step_api(n, plan)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    run(args.warmup)
-    torch.cuda.synchronize()
-    launches[0] = 0
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize(); barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall, dev_ms = float(tmax[0].item()), float(tmax[1].item())
-
-    # ---- secondary measurement: the step API (one kernel launch per env.step, hipGraph replay)
-    step_api = None
-    if args.mode == "rollout" and not args.no_step_api:
-        K2 = max(P, min(args.steps, 4000) // P * P)
-        plan2 = env.make_plan(P, ring, env.reward, env.flags)
-        run_step_api(P, plan2)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier(); torch.cuda.synchronize()
-        w0 = time.perf_counter(); e0.record()
-        run_step_api(K2, plan2)
-        e1.record(); torch.cuda.synchronize(); barrier()
-        w2 = time.perf_counter() - w0
-        tm2 = torch.tensor([w2, e0.elapsed_time(e1)], dtype=torch.float64, device=comm_dev)
-        if world > 1:
-            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
-        step_api = (K2, float(tm2[0].item()), float(tm2[1].item()))
-        plan2.close()
+    # ---- headline: workload resident in HBM before the timed region
+    wl = Workload(ni, torch, key, B, device, rank, args.mode, P, args.ring, args.outputs, args.traj)
+    wall, dev_ms = timed(torch, dist, world, comm_dev, wl, K, W)
+    roof = roofline_of(wl, K, dev_ms)
+    total, tally_check = gathered_tally(torch, dist, world, comm_dev, wl)
 
     if args.calibrate:   # known-size dword-per-lane copies for the PMC byte calibration (profiles/)
-        cal = torch.empty(S, env.ld, dtype=torch.float32, device=device)
+        cal = torch.empty(wl.S, wl.env.ld, dtype=torch.float32, device=device)
         for _ in range(20):
-            ni._lib.check(env._L.nig_get_state(env._h, cal.data_ptr(), env.ld, None, env._stream()))
+            ni._lib.check(wl.env._L.nig_get_state(wl.env._h, cal.data_ptr(), wl.env.ld, None, wl.env._stream()))
         torch.cuda.synchronize()
+    S, A = wl.S, wl.A
+    wl.close()
+    del wl
 
-    # ---- the path's one exchange: final tally reduction (after the timed region)
-    from neorl_industrial_gym_amd.parallel import all_reduce_partial
-    total = all_reduce_partial(env.reduce_tally().to(comm_dev)).cpu().numpy()
-    L = ni._lib
+    # ---- secondary: the step API (one kernel launch per env.step, hipGraph replay of P of them)
+    step_api = None
+    if args.mode == "rollout" and not args.no_step_api:
+        w2 = Workload(ni, torch, key, B, device, rank, "graph", P, args.ring, args.outputs, args.traj)
+        K2 = max(2, min(K, 8))
+        sw, sd = timed(torch, dist, world, comm_dev, w2, K2, 1)
+        r2 = roofline_of(w2, K2, sd)
+        step_api = {"value": K2 * P * B * world / sw, "unit": "env-steps/s", "steps": K2, "launch_us": r2["launch_us"],
+                    "alg_bytes_per_env_step": r2["alg_bytes_per_env_step"], "achieved_GBps": r2["achieved"],
+                    "frac_of_hbm_peak": r2["frac"], "traffic": r2["traffic"],
+                    "note": f"one step_kernel launch per env.step, {P} per hipGraph replay"}
+        w2.close()
+        del w2
+
+    # ---- secondary: PowerGrid-v0, 262144 lanes per GPU (BASELINE configs[2]; configs[4] = this at N = 8)
+    powergrid = None
+    if key == "cr" and args.mode == "rollout" and not args.no_powergrid:
+        Bp = BASELINE_BATCH["pg"]
+        w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, min(args.ring, 16), args.outputs, args.traj)
+        K3 = max(2, min(K, 8))
+        pw, pd = timed(torch, dist, world, comm_dev, w3, K3, 2)
+        r3 = roofline_of(w3, K3, pd)
+        ptotal, pcheck = gathered_tally(torch, dist, world, comm_dev, w3)
+        L = ni._lib
+        powergrid = {"workload": f"PowerGrid-v0, batch={Bp} per GPU x {world} GPU(s) = {Bp * world} lanes, fused rollout, "
+                                 f"{P} env.step per launch, outputs: {args.outputs}",
+                     "value": K3 * P * Bp * world / pw, "unit": "env-steps/s", "steps": K3, "ms_per_step": pw * 1e3 / K3,
+                     "roofline": r3, "tally": {"episodes": int(ptotal[L.T_EPISODES]), "violations": int(ptotal[L.T_VIOL]),
+                                               "critical": int(ptotal[L.T_CRIT])}, "tally_check": pcheck}
+        w3.close()
+        del w3
 
     if rank == 0:
-        steps_total = args.steps * B * world
-        value = steps_total / wall
-        rollout_mode = args.mode == "rollout"
-        bytes_step = alg_bytes_rollout(S, A, args.outputs) if rollout_mode else alg_bytes_per_step(S, A)
-        n_launch = max(launches[0], 1) if not rollout_mode else (args.steps // P + (1 if args.steps % P else 0))
-        steps_per_launch = args.steps / n_launch
-        launch_us = dev_ms * 1e3 / n_launch                     # HIP events over the timed region / launches
-        # algorithmic bytes per launch = SURVEY 8(d) per-env-step figure x env-steps one launch processes
-        achieved = bytes_step * B * steps_per_launch / (launch_us * 1e-6) / 1e9    # GB/s
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{key}_{B}_{args.mode}_{args.outputs if rollout_mode else 'step'}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        L = ni._lib
         out = {
             "metric": "env-steps/sec (whole node) + safety-violation-count parity, ChemicalReactor-v0"
                       if key == "cr" else f"env-steps/sec (whole node), {ENVS[key]}",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": K * P * B * world / wall, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU, "
-                                   + (f"fused rollout kernel ({P} env.step per launch, state in registers, "
+            "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU; one bench step = "
+                                   + (f"one fused rollout launch of {P} env.step per lane (state in registers, "
                                       f"per-step outputs: {args.outputs})"
                                       if args.mode == "rollout" else
-                                      f"step-API (one fused step kernel per env.step), {args.mode} launch"
-                                      + (f" ({P} steps per hipGraph replay)" if plan is not None else "")),
-                       "batch_per_gpu": B, "global_batch": B * world, "action_ring": R,
-                       "autoreset": True, "episode_tally": True,
+                                      f"{P} step-API launches (one fused step kernel per env.step), {args.mode}"),
+                       "batch_per_gpu": B, "global_batch": B * world, "plan_steps": P, "env_steps_per_step": P * B * world,
+                       "action_ring": args.ring, "autoreset": True, "episode_tally": True,
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("rollout_kernel<%s>" if args.mode == "rollout" else "step_kernel<%s,false>")
-                                   % {"cr": "ChemicalReactor", "pg": "PowerGrid", "ra": "RobotAssembly"}[key],
-                         "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": B * steps_per_launch,
-                         "alg_bytes_per_launch": bytes_step * B * steps_per_launch, "launch_us": launch_us,
-                         "bytes_model": ("fused-rollout figure (SURVEY 8d): action read + requested per-step outputs"
-                                         if rollout_mode else "step-API figure (SURVEY 8d): 8S+4A+16")},
+            "roofline": roof,
             "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
                       "critical": int(total[L.T_CRIT]), "return_mean": float(total[L.T_RET_SUM] / max(total[L.T_EPISODES], 1))},
+            "tally_check": tally_check,
         }
         if step_api is not None:
-            K2, w2, d2 = step_api
-            b2 = alg_bytes_per_step(S, A)
-            out["step_api"] = {"value": K2 * B * world / w2, "unit": "env-steps/s", "steps": K2,
-                               "launch_us": d2 * 1e3 / K2, "alg_bytes_per_env_step": b2,
-                               "achieved_GBps": b2 * B / (d2 * 1e-3 / K2) / 1e9,
-                               "frac_of_hbm_peak": b2 * B / (d2 * 1e-3 / K2) / 1e9 / HBM_PEAK_GBS,
-                               "note": "one step_kernel launch per env.step, hipGraph replay"}
+            out["step_api"] = step_api
+        if powergrid is not None:
+            out["powergrid"] = powergrid
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as O
-            cores = max(1, min(os.cpu_count() or 1, 64))
-            try:
-                cores = min(cores, len(os.sched_getaffinity(0)))
-            except Exception:
-                pass
-            # calibrate, then a bounded sample of the SAME workload (same lanes, seeds, policy, auto-reset)
-            c0 = time.perf_counter()
-            O.rollout(key, B, 4, seed=seed, flavor=O.MATH_LIBM, nthreads=cores)
-            per_step = (time.perf_counter() - c0) / 4
-            Tc = int(max(8, min(2000, args.cpu_seconds / max(per_step, 1e-6))))
-            c0 = time.perf_counter()
-            _, _, tot, _ = O.rollout(key, B, Tc, seed=seed, flavor=O.MATH_LIBM, nthreads=cores)
-            cw = time.perf_counter() - c0
-            out["cpu_baseline"] = {"value": tot.steps / cw, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{B} lanes x {Tc} steps of the same workload (oracle/nig_oracle.c, "
-                                             f"OpenMP over lanes, libm math), {cw:.2f} s wall"}
+            out["cpu_baseline"] = cpu_baseline(key, B, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -319,19 +404,23 @@ MIXED7_SURVEY = [("ChemicalReactor-v0", 12, 3, "reference"), ("PowerGrid-v0", 32
 
 def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     """BASELINE config 4: the README's seven environments (README.md:24-32) in ONE padded SoA batch of
-    --batch lanes (default 1 048 576), contiguous 256-aligned segments of equal size, one rollout
-    kernel per segment on its own stream.  Three of the seven exist upstream and are parity-checked
-    against the reference; four are README-only there and run build-specified plants (flagged per env).
-    Reports total and per-env throughput; the HBM figure is the lane-weighted fused-rollout byte count
-    with reward+flags outputs."""
+    --batch lanes (default 1 048 576), contiguous 256-aligned segments of equal size.  --mixed-launch
+    fused: ONE kernel launch over all segments (block -> env table, heaviest envs first);
+    streams: one rollout kernel per segment on its own stream (round-1 form).  Three of the seven
+    exist upstream and are parity-checked against the reference; four are README-only there and run
+    build-specified plants (flagged per env).  Reports total and per-env throughput; the HBM figure is
+    the lane-weighted fused-rollout byte count with reward+flags outputs."""
     B = args.batch or 1048576
     per = (B // 7) // 256 * 256
     envset = MIXED7 if args.mixed_set == "readme" else MIXED7_SURVEY
     counts = [(name, per if i else B - 6 * per) for i, (name, _, _, _) in enumerate(envset)]
     dims = {name: (S, A) for name, S, A, _ in envset}
     origin = {name: o for name, _, _, o in envset}
-    mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B)
-    R, P = min(args.ring, 16), max(1, min(args.plan_steps, args.steps))
+    fused = args.mixed_launch == "fused"
+    mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B,
+                             fused=fused)
+    P, K, W = max(1, args.plan_steps), max(1, args.steps), max(0, args.warmup)
+    R = min(args.ring, 16)
     ring = torch.zeros(R, mix.A_max, mix.ld, dtype=torch.float32, device=device)
     for s in range(R):
         mix.fill_actions(1000 + s, ring[s])
@@ -339,33 +428,14 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     fl = torch.empty(P, mix.ld, dtype=torch.int32, device=device)
     mix.reset()
 
-    def run(n):
-        full, rem = divmod(n, P)
-        for _ in range(full):
+    class _W:
+        def launch(self):
             mix.rollout(P, ring, rew, fl)
-        if rem:
-            mix.rollout(rem, ring, rew, fl)
-
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter(); ev0.record()
-    run(args.steps)
-    ev1.record(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    tm = torch.tensor([wall, ev0.elapsed_time(ev1)], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    wall, dev_ms = float(tm[0]), float(tm[1])
-    # per-env rate measured separately on its own segment size (same kernels)
+    wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W)
+    # per-env rate measured separately on its own segment size (same per-env kernels, stand-alone launch)
     per_env = {}
-    for (name, n), seg in zip(counts, mix.envs):
-        o = mix.offsets[mix.envs.index(seg)]
-        reps = max(1, args.steps // P // 4)
+    for (name, n), seg, o in zip(counts, mix.envs, mix.offsets):
+        reps = max(1, K // 4)
         torch.cuda.synchronize(); c0 = time.perf_counter()
         for _ in range(reps):
             seg.rollout(P, ring[:, :seg.action_dim, o:o + n], rew[:, o:o + n], fl[:, o:o + n])
@@ -375,19 +445,21 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
                          "dynamics": origin[name], "reference_parity": origin[name] == "reference"}
     if rank == 0:
         bytes_launch = sum((4 * v["action_dim"] + 8) * v["lanes"] for v in per_env.values()) * P
-        n_launch = args.steps // P + (1 if args.steps % P else 0)
-        launch_us = dev_ms * 1e3 / n_launch
+        launch_us = dev_ms * 1e3 / K
         achieved = bytes_launch / (launch_us * 1e-6) / 1e9
         print(json.dumps({
-            "metric": "env-steps/sec (whole node), all 7 envs mixed-batch", "value": args.steps * B * world / wall,
-            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "env-steps/sec (whole node), all 7 envs mixed-batch", "value": K * P * B * world / wall,
+            "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"mixed padded-SoA batch of {B} lanes per GPU (S_max={mix.S_max}, A_max={mix.A_max}): "
-                                   + ", ".join(f"{n} x {e}" for e, n in counts) + f"; fused rollout, {P} env.step per launch, "
-                                   "reward+flags outputs", "batch_per_gpu": B, "segments": counts},
+                                   + ", ".join(f"{n} x {e}" for e, n in counts) + f"; one bench step = {P} env.step per lane, "
+                                   + ("ONE fused launch over all segments" if fused else "one launch per segment on 7 streams")
+                                   + ", reward+flags outputs", "batch_per_gpu": B, "plan_steps": P,
+                       "env_steps_per_step": P * B * world, "segments": counts, "launch": args.mixed_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<*,1> x7 (concurrent streams)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mixed_rollout_kernel<1>" if fused else "rollout_kernel<*,1> x7 (concurrent streams)",
                          "alg_bytes_per_launch": bytes_launch, "launch_us": launch_us,
                          "bytes_model": "fused-rollout figure: action read + reward + flag word per env-step, lane-weighted"},
             "per_env": per_env}))

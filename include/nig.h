@@ -91,6 +91,9 @@ enum {
     NIG_T_CRIT,           /* sum of SafetyMetrics.critical_violations            utils.py:142 */
     NIG_T_SHUTDOWN,       /* steps with info['critical_shutdown']                utils.py:143 */
     NIG_T_SUCCESS,        /* episodes with return > 0                            utils.py:150 */
+    NIG_T_SATISFIED,      /* sum over steps of SafetyMetrics.constraints_satisfied  utils.py:109 (numerator)   */
+    NIG_T_CONSTRAINTS,    /* sum over steps of SafetyMetrics.total_constraints      utils.py:109 (denominator):
+                             constraint_satisfaction_rate (utils.py:144-147) = SATISFIED / CONSTRAINTS, 1.0 if 0 */
     NIG_T_ROWS
 };
 
@@ -280,7 +283,12 @@ typedef struct nig_policy {
     float setpoint[NIG_MAX_ACTION_DIM];
 } nig_policy;
 
-/* Install the policy used by nig_rollout_policy (copied to device memory owned by the handle). */
+/* Install the policy used by nig_rollout_policy (copied to device memory owned by the handle).
+ * A PID policy owns per-lane controller memory (integral, previous error: float [2*A][ld], device
+ * memory of the handle, zeroed when a PID policy is installed = the agent's constructor,
+ * baseline_agents.py:55-57).  It persists across launches and across nig_reset -- upstream never
+ * resets the integral either (baseline_agents.py:61-80) -- so a rollout cut into several launches
+ * equals one launch. */
 int nig_set_policy(nig_handle *h, const nig_policy *policy /* host */, void *stream);
 
 /*
@@ -346,6 +354,9 @@ int nig_get_state(nig_handle *h, float *state, int64_t ld, uint32_t *ctr, void *
  * the SafetyMetrics of the last step, base.py:94-124): int32 [5][ld_out] rows =
  * constraints_satisfied, total_constraints, violation_count, critical_violations,
  * and safety_score*total (== satisfied), decoded from a flag array of the last step.
+ * total_constraints = the handle's ENABLED built-in constraints (nig_env_spec.n_constraints minus
+ * those removed with nig_set_constraint_mask; 4 for AdvancedChemicalReactor); violation_count
+ * includes NIG_FLAG_NVIOL_HI.
  */
 int nig_get_safety_metrics(nig_handle *h, const uint32_t *flags, int32_t *out, int64_t ld_out,
                            void *stream);

@@ -1,19 +1,50 @@
-"""Build libnig.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+"""Build libnig.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+One translation unit per environment (csrc/env_*.hip) plus the C ABI (csrc/nig_api.hip), compiled
+in parallel and linked into ONE shared library.  Staleness is decided by a content hash of the
+sources (mtimes do not survive a snapshot copy to another machine), stored next to the library.
+"""
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "nig_kernels.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "nig_envs.hpp"), os.path.join(_HERE, "csrc", "nig_detmath.hpp"),
-        os.path.join(os.path.dirname(_HERE), "include", "nig.h")]
+CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(_HERE, "libnig.so")
+STAMP = LIB + ".srchash"
 
 # -ffp-contract=off: NumPy evaluates a*b+c with two roundings; the parity bar is bit-level.
 # -fno-slp-vectorize: hipcc packs neighbouring scalar f32 adds/muls into v_pk_* pairs; the moves that
 # gather their operands cost more issue slots than the packing saves (fused rollout -3 % with SLP on).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
                "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc"))
+                  + [os.path.join(os.path.dirname(_HERE), "include", "nig.h")])
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def source_hash():
+    return _digest(sources() + headers(), " ".join(HIPCC_FLAGS))
 
 
 def find_hipcc():
@@ -24,21 +55,79 @@ def find_hipcc():
 
 
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/ -> libnig.so.  Cross-compiles without a GPU."""
+def _compile_one(hipcc, src, hdr_hash, verbose):
+    """Compile one translation unit unless its object is current; returns the object path."""
+    name = os.path.splitext(os.path.basename(src))[0]
+    obj = os.path.join(OBJ, name + ".o")
+    stamp = obj + ".srchash"
+    want = _digest([src], hdr_hash)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return obj
+    cmd = [hipcc] + HIPCC_FLAGS + ["-c", "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/*.hip -> libnig.so.  Cross-compiles without a GPU.  The library is written to a
+    temporary name and renamed into place, so a concurrent reader never maps a half-written file."""
     if not force and not stale():
         return LIB
     hipcc = find_hipcc()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libnig.so (no CPU fallback exists)")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, SRC]
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in glob.glob(os.path.join(OBJ, "*.srchash")):
+            os.remove(f)
+    hdr_hash = _digest(headers(), " ".join(HIPCC_FLAGS))
+    srcs = sources()
+    jobs = jobs or max(1, min(len(srcs), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile_one(hipcc, s, hdr_hash, verbose), srcs))
+    tmp = f"{LIB}.tmp.{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
+
+
+def ensure(verbose=False):
+    """What importing the package calls.  Never compiles inside a profiled or GPU-initialised
+    process: with NIG_NO_AUTOBUILD set, or under a rocprofiler preload, a stale library is an error
+    (build first: `python -c 'import __graft_entry__ as g; g.build()'`).  Under torchrun only
+    LOCAL_RANK 0 compiles; the other ranks wait for its stamp."""
+    if not stale():
+        return LIB
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    if os.environ.get("NIG_NO_AUTOBUILD") or "rocprof" in preload:
+        raise ImportError(f"{LIB} is missing or stale and auto-build is disabled (NIG_NO_AUTOBUILD / profiler preload): "
+                          "run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    if find_hipcc() is None:
+        if os.path.exists(LIB):
+            return LIB                     # no compiler on this machine: use the library that travelled with the tree
+        raise ImportError(f"{LIB} is missing and hipcc was not found; this package has no CPU fallback")
+    if int(os.environ.get("LOCAL_RANK", "0")) != 0:
+        deadline = time.time() + 900
+        while stale():
+            if time.time() > deadline:
+                raise ImportError("timed out waiting for LOCAL_RANK 0 to build libnig.so")
+            time.sleep(0.5)
+        return LIB
+    return build(verbose=verbose)

@@ -19,10 +19,11 @@ F_AUTORESET, F_TALLY = 0x1, 0x2
 FLAG_TERMINATED, FLAG_TRUNCATED = 0x1, 0x2
 FLAG_VIOL_SHIFT, FLAG_NVIOL_SHIFT, FLAG_NCRIT_SHIFT = 2, 5, 7
 FLAG_SHUTDOWN, FLAG_DID_RESET, FLAG_INACTIVE, FLAG_STEP_SHIFT = 0x200, 0x400, 0x800, 16
+FLAG_VIOL3, FLAG_NVIOL_HI = 0x1000, 0x2000
 CTR_STEP_MASK, CTR_DONE, CTR_VIOL_SHIFT = 0x7FFF, 0x8000, 16
 MAX_EPISODE_STEPS = 21845
 (T_EPISODES, T_RET_SUM, T_RET_SQ, T_RET_MIN, T_RET_MAX, T_LEN_SUM, T_LEN_SQ, T_VIOL, T_CRIT,
- T_SHUTDOWN, T_SUCCESS, T_ROWS) = range(12)
+ T_SHUTDOWN, T_SUCCESS, T_SATISFIED, T_CONSTRAINTS, T_ROWS) = range(14)
 
 SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
@@ -64,13 +65,13 @@ _lib = None
 
 
 def lib():
-    """Load libnig.so (building it first if the sources are newer and hipcc exists)."""
+    """Load libnig.so.  A stale or missing library is rebuilt first (content hash of csrc/), except
+    inside a profiled process or with NIG_NO_AUTOBUILD set, where that is an ImportError (_build.ensure)."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.stale() and _build.find_hipcc():
-        _build.build()
+    _build.ensure()
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -529,7 +529,7 @@ class MixedBatchedEnv:
     launches one kernel per segment, each on its own HIP stream."""
 
     def __init__(self, segments, device="cuda:0", seed: int = 0x5EED, autoreset: bool = True, tally: bool = False,
-                 env_index0: int = 0):
+                 env_index0: int = 0, fused: bool = False):
         self.device = torch.device(device)
         segs = list(segments.items()) if isinstance(segments, dict) else list(segments)
         self.S_max = max(int(_lib.env_spec(ENV_IDS[e]).state_dim) for e, _ in segs)

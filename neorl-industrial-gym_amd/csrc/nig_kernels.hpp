@@ -1,4 +1,4 @@
-// nig_kernels.hip -- HIP kernels (gfx950) and C-ABI of libnig.so.
+// nig_kernels.hpp -- HIP kernel templates (gfx950) of libnig.so, one instantiation set per environment.
 //
 // One wavefront lane per environment instance.  State, actions, noise and outputs are
 // structure-of-arrays ([row][lane], row pitch ld) so every global access of a wave is one
@@ -8,7 +8,11 @@
 // shutdown -> (optional) episode tally flush and in-kernel auto-reset.  No MFMA: these are
 // elementwise ODE updates (HBM-bound, DESIGN.md "Roofline").
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build).
+// Translation units: every environment's kernels are instantiated in a file of their own
+// (env_*.hip: `NIG_DEFINE_ENV_LAUNCH(Env, name)`), the C ABI and the env-independent kernels
+// live in nig_api.hip; _build.py compiles them in parallel and links libnig.so.
+// Build flags: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -59,7 +63,12 @@ struct StepArgs {
     uint64_t env0; uint32_t seed_lo, seed_hi;
     const uint32_t *t_ptr; uint32_t t_off;   // launch counter t = (t_ptr ? *t_ptr : 0) + t_off (graph replay keeps t on the device)
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
+    int n_en;                         // enabled built-in constraints = SafetyMetrics.total_constraints of every step (base.py:115)
 };
+// internal bit of StepArgs::hflags (above the public NIG_F_* bits): some lane of the handle may hold
+// NIG_CTR_DONE although the handle auto-resets (never reset, left out by reset(mask), set by
+// nig_set_state); cleared by a full nig_reset.  Lets the rollout kernel keep its no-freeze fast path.
+constexpr uint32_t HF_MAY_HOLD_DONE = 0x10000u;
 
 // IndustrialEnv.step for one lane, entirely in registers (base.py:157-213): action clip, constraint
 // check on the pre-state and dynamics, then post_core = reward / penalties / termination on the
@@ -174,7 +183,7 @@ __device__ __forceinline__ void draw_one(const RngKey &k, double (&n)[Env::KS > 
 
 // Episode bookkeeping of one finished episode (utils.py:120-125), lane-private column of the tally.
 // All 11 rows are loaded before any is stored: one memory round trip instead of eleven dependent ones.
-__device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, int step, uint32_t viol_ep, int ncrit)
+__device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, int step, uint32_t viol_ep, int ncrit, int n_en)
 {
     double v[NIG_T_ROWS];
 #pragma unroll
@@ -191,6 +200,8 @@ __device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, 
     v[NIG_T_CRIT] += (double)ncrit;            // a critical step always ends the episode
     v[NIG_T_SHUTDOWN] += (ncrit > 0) ? 1.0 : 0.0;
     v[NIG_T_SUCCESS] += (ret > 0.0) ? 1.0 : 0.0;
+    v[NIG_T_SATISFIED] += (double)(n_en * step - (int)viol_ep);   // sum over the episode's steps of constraints_satisfied
+    v[NIG_T_CONSTRAINTS] += (double)(n_en * step);
 #pragma unroll
     for (int r = 0; r < NIG_T_ROWS; ++r) T[(size_t)r * ld] = v[r];
 }
@@ -216,7 +227,7 @@ struct LaneTally {
     // merge into the lane's column of the global tally (same fp64 operation order per row as
     // flush_tally would have produced when at most one episode finished; sums of several
     // episodes are added as one partial -- integer rows exact, fp rows within 1 ulp of fp64)
-    __device__ __forceinline__ void merge(double *T, uint32_t ld) const
+    __device__ __forceinline__ void merge(double *T, uint32_t ld, int n_en) const
     {
         double v[NIG_T_ROWS];
 #pragma unroll
@@ -232,6 +243,8 @@ struct LaneTally {
         v[NIG_T_CRIT] += (double)crit;
         v[NIG_T_SHUTDOWN] += (double)shutdown;
         v[NIG_T_SUCCESS] += (double)success;
+        v[NIG_T_SATISFIED] += (double)((long long)n_en * len_sum - viol);   // every step of a finished episode has n_en constraints
+        v[NIG_T_CONSTRAINTS] += (double)((long long)n_en * len_sum);
 #pragma unroll
         for (int r = 0; r < NIG_T_ROWS; ++r) T[(size_t)r * ld] = v[r];
     }
@@ -333,7 +346,7 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
         }
         if (done) {
             (p.life_viol + base)[tid] += (long long)viol_ep;   // base.py:183 total_violations (never reset)
-            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en); ret = 0.0; }
             if (p.final_obs) {
                 float *fo = p.final_obs + base;
 #pragma unroll
@@ -489,7 +502,9 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     float *obs_row = nullptr;                  // this step's observation block / rows
     if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S;
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
-    const bool may_freeze = !autoreset || base + BLOCK > p.B;   // block-uniform: lanes can be frozen (finished, or out of range)
+    // block-uniform: lanes can be frozen (finished and waiting for reset -- also on an auto-reset handle whose lanes
+    // were never reset, left out by reset(mask) or marked done by set_state: base.py:159-160 -- or out of range)
+    const bool may_freeze = !autoreset || (p.hflags & HF_MAY_HOLD_DONE) != 0 || base + BLOCK > p.B;
 
     auto one_step = [&](auto pos_tag, float (&abuf)[A], double (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
@@ -695,7 +710,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
     if (tally) {
         (p.ep_ret + base)[tid] = (double)ret;
-        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld);
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
     }
 }
 
@@ -707,6 +722,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 struct PolicyArgs {
     StepArgs s;
     const nig_policy *pol;      // device copy
+    float *pid;                 // PID policies: per-lane controller memory [2*A][ld] (integral rows, then previous-error rows)
     int n_steps;
     uint32_t out_stride;
     float *obs_out; uint64_t obs_step_stride;                        // row-major [B][S] per step, pre-step obs
@@ -813,8 +829,14 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     double nz[KSN];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[tid];
+    // PID memory lives in the handle (baseline_agents.py:55-80: integral and previous error are the agent's,
+    // never reset): loaded here, stored at the end, so launches chain exactly
+    const bool pid_mem = q.pid != nullptr && pol->kind == NIG_POLICY_PID;
 #pragma unroll
-    for (int j = 0; j < A; ++j) { integ[j] = 0.0f; eprev[j] = 0.0f; }
+    for (int j = 0; j < A; ++j) {
+        integ[j] = pid_mem ? (q.pid + base + (size_t)j * p.ld)[tid] : 0.0f;
+        eprev[j] = pid_mem ? (q.pid + base + (size_t)(A + j) * p.ld)[tid] : 0.0f;
+    }
     double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
     LaneTally lt;
     lt.clear();
@@ -902,7 +924,14 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
     if (tally) {
         (p.ep_ret + base)[tid] = ret;
-        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld);
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
+    }
+    if (pid_mem) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            (q.pid + base + (size_t)j * p.ld)[tid] = integ[j];
+            (q.pid + base + (size_t)(A + j) * p.ld)[tid] = eprev[j];
+        }
     }
 }
 
@@ -1102,7 +1131,7 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     if (lt.life != 0) p.life_viol[li] += lt.life;
     if (tally) {
         p.ep_ret[li] = ret;
-        if (lt.episodes > 0) lt.merge(p.tally + li, p.ld);
+        if (lt.episodes > 0) lt.merge(p.tally + li, p.ld, p.n_en);
     }
 }
 
@@ -1153,181 +1182,33 @@ __global__ void __launch_bounds__(BLOCK) fill_actions_kernel(float *act, int64_t
         act[(int64_t)k * ld_act + i] = (float)((double)Env::act_low(k) + ((double)Env::act_high(k) - (double)Env::act_low(k)) * u[k]);
 }
 
-__global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long *life, double *ep_ret, double *tally,
-                                                        int64_t ld, int64_t B)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= ld) return;
-    ctr[i] = (i < B) ? NIG_CTR_DONE : NIG_CTR_DONE;   // nothing steps before the first reset
-    life[i] = 0;
-    if (ep_ret) ep_ret[i] = 0.0;
-    if (tally) {
-#pragma unroll
-        for (int r = 0; r < NIG_T_ROWS; ++r) tally[(int64_t)r * ld + i] = 0.0;
-        tally[(int64_t)NIG_T_RET_MIN * ld + i] = __builtin_inf();
-        tally[(int64_t)NIG_T_RET_MAX * ld + i] = -__builtin_inf();
-    }
-}
-
-__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
-
-__global__ void __launch_bounds__(BLOCK) safety_metrics_kernel(const uint32_t *flags, int32_t *out, int64_t ld_out,
-                                                               int64_t B)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= B) return;
-    const uint32_t f = flags[i];
-    const int nv = (int)((f >> NIG_FLAG_NVIOL_SHIFT) & 3u), nc = (int)((f >> NIG_FLAG_NCRIT_SHIFT) & 3u);
-    out[0 * ld_out + i] = 3 - nv;   // constraints_satisfied   base.py:96-106
-    out[1 * ld_out + i] = 3;        // total_constraints       base.py:115
-    out[2 * ld_out + i] = nv;       // violation_count
-    out[3 * ld_out + i] = nc;       // critical_violations
-    out[4 * ld_out + i] = 3 - nv;   // safety_score * total    base.py:116
-}
-
-// deterministic two-stage reduction of the tally rows: fixed grid, fixed tree order
-__global__ void __launch_bounds__(BLOCK) reduce_tally_stage1(const double *tally, int64_t ld, int64_t B, double *scratch)
-{
-    __shared__ double sh[BLOCK];
-    for (int r = 0; r < NIG_T_ROWS; ++r) {
-        const bool is_min = (r == NIG_T_RET_MIN), is_max = (r == NIG_T_RET_MAX);
-        double acc = is_min ? __builtin_inf() : (is_max ? -__builtin_inf() : 0.0);
-        for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < B; i += (int64_t)gridDim.x * BLOCK) {
-            const double v = tally[(int64_t)r * ld + i];
-            acc = is_min ? fmin(acc, v) : (is_max ? fmax(acc, v) : acc + v);
-        }
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (int w = BLOCK / 2; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) {
-                const double o = sh[threadIdx.x + w];
-                sh[threadIdx.x] = is_min ? fmin(sh[threadIdx.x], o) : (is_max ? fmax(sh[threadIdx.x], o) : sh[threadIdx.x] + o);
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) scratch[(int64_t)blockIdx.x * NIG_T_ROWS + r] = sh[0];
-        __syncthreads();
-    }
-}
-
-__global__ void reduce_tally_stage2(const double *scratch, int nblk, double *out)
-{
-    const int r = threadIdx.x;
-    if (r >= NIG_T_ROWS) return;
-    const bool is_min = (r == NIG_T_RET_MIN), is_max = (r == NIG_T_RET_MAX);
-    double acc = is_min ? __builtin_inf() : (is_max ? -__builtin_inf() : 0.0);
-    for (int b = 0; b < nblk; ++b) {
-        const double v = scratch[(int64_t)b * NIG_T_ROWS + r];
-        acc = is_min ? fmin(acc, v) : (is_max ? fmax(acc, v) : acc + v);
-    }
-    out[r] = acc;
-}
-
-__global__ void __launch_bounds__(BLOCK) copy_rows_kernel(const float *src, int64_t ld_src, float *dst, int64_t ld_dst,
-                                                          int rows, int64_t B)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= B) return;
-    for (int k = 0; k < rows; ++k) dst[(int64_t)k * ld_dst + i] = src[(int64_t)k * ld_src + i];
-}
 
 }  // namespace nig
 
 // =====================================================================================
-// host side: C ABI
+// host side: per-environment launch table.  Each env_*.hip instantiates its kernels through
+// NIG_DEFINE_ENV_LAUNCH; nig_api.hip reaches them through these function pointers only.
 // =====================================================================================
-using namespace nig;
+namespace nig {
 
-struct nig_handle {
-    int env;
-    int device;
-    int64_t B;
-    uint64_t seed, env0;
-    int max_steps;
-    double dt;
-    uint32_t flags;
-    uint32_t t;            // RNG launch counter
-    uint32_t cmask;        // enabled built-in constraints (bit k)
-    nig_layout lay;
-    char *ws;
-    bool owns_ws;
-    double *scratch;       // reduce scratch [REDUCE_BLOCKS][NIG_T_ROWS] (inside workspace tail)
-    uint32_t *t_dev;       // device copy of t read by graph-replayed step kernels
-    float *state;          // state rows: inside the workspace, or an array bound by the caller
-    int64_t ld_state;
-    nig_policy *pol_dev;   // device copy of the installed policy
-    nig_policy pol_host;   // staging copy (must outlive the async H2D copy)
-    bool has_policy;
-    float *mlp_stream;     // device copy of the MFMA operand stream of the MLP actor (owned)
-    char *hst_pinned;      // host-buffer entry points: pinned staging + its device mirror (owned, lazy)
-    char *hst_dev;
-    size_t hst_bytes;
+struct EnvLaunch {
+    void (*step)(const StepArgs &, bool parity, unsigned grid, hipStream_t);
+    void (*rollout)(int out_mode, const RolloutArgs &, uint32_t t0, unsigned grid, hipStream_t);
+    void (*policy)(const PolicyArgs &, unsigned grid, hipStream_t);
+    void (*mlp)(const MlpArgs &, unsigned grid, hipStream_t);      // nullptr: env shape not supported by the MFMA actor
+    void (*reset)(const ResetArgs &, bool parity, unsigned grid, hipStream_t);
+    void (*fill)(float *act, int64_t ld_act, int64_t B, uint64_t env0, uint32_t seed_lo, uint32_t seed_hi, uint32_t t,
+                 unsigned grid, hipStream_t);
 };
-
-struct nig_plan {
-    nig_handle *h;
-    int n_steps;
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-};
-
-static unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
-
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, const char *detail = "")
-{
-    snprintf(g_err, sizeof g_err, fmt, detail);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                        \
-    do {                                                                     \
-        hipError_t e_ = (expr);                                              \
-        if (e_ != hipSuccess) return fail(NIG_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
-    } while (0)
-
-static const nig_env_spec SPECS[NIG_NUM_ENVS] = {
-    {12, 3, 3, 500, 2, 8, 0.1, {-100.0, -50.0, -25.0}, {1, 1, 0}, 1},
-    {32, 8, 3, 1000, 23, 31, 0.1, {-50.0, -30.0, -20.0}, {1, 1, 0}, 0},
-    {24, 7, 3, 1000, 0, 7, 0.1, {-100.0, -200.0, -50.0}, {1, 1, 0}, 0},
-    /* Advanced envs: 4 / 3 safety-metric conditions, no penalties through the base loop, deterministic */
-    {20, 6, 4, 1000, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
-    {32, 8, 3, 500, 0, 0, 0.1, {0.0, 0.0, 0.0}, {0, 0, 0}, 0},
-    /* build-specified plants (spec_plants.py): dims and constraint tables come from the generated data */
-#define NIG_SPEC_ROW(K) {SpecPlant<K>::S, SpecPlant<K>::A, 3, SpecPlant<K>::MAX_STEPS, SpecPlant<K>::KS, SpecPlant<K>::KR, 0.1, \
-                         {NIG_SPEC_PLANTS[K].pen[0], NIG_SPEC_PLANTS[K].pen[1], NIG_SPEC_PLANTS[K].pen[2]},                    \
-                         {NIG_SPEC_PLANTS[K].crit[0], NIG_SPEC_PLANTS[K].crit[1], NIG_SPEC_PLANTS[K].crit[2]}, 1}
-    NIG_SPEC_ROW(0), NIG_SPEC_ROW(1), NIG_SPEC_ROW(2), NIG_SPEC_ROW(3),
-#undef NIG_SPEC_ROW
-};
-static const char *NAMES[NIG_NUM_ENVS] = {"ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0",
-                                          "AdvancedChemicalReactor-v0", "AdvancedPowerGrid-v0",
-                                          "HVACControl-v0", "WaterTreatment-v0", "SteelAnnealing-v0", "SupplyChain-v0"};
-
-// run `F<Env>(args...)` for the env type behind a run-time id
-#define NIG_DISPATCH_ENV(env_id, CALL)                                      \
-    switch (env_id) {                                                       \
-    case NIG_ENV_CHEMICAL_REACTOR: { using E = ChemicalReactor; CALL; } break;          \
-    case NIG_ENV_POWER_GRID: { using E = PowerGrid; CALL; } break;                      \
-    case NIG_ENV_ROBOT_ASSEMBLY: { using E = RobotAssembly; CALL; } break;              \
-    case NIG_ENV_ADV_CHEMICAL_REACTOR: { using E = AdvancedChemicalReactor; CALL; } break; \
-    case NIG_ENV_ADV_POWER_GRID: { using E = AdvancedPowerGrid; CALL; } break;          \
-    case NIG_ENV_HVAC_CONTROL: { using E = HVACControl; CALL; } break;                  \
-    case NIG_ENV_WATER_TREATMENT: { using E = WaterTreatment; CALL; } break;            \
-    case NIG_ENV_STEEL_ANNEALING: { using E = SteelAnnealing; CALL; } break;            \
-    default: { using E = SupplyChain; CALL; } break;                        \
-    }
 
 template <class Env>
-static void launch_reset(const ResetArgs &a, bool parity, hipStream_t st)
+static void launch_reset(const ResetArgs &a, bool parity, unsigned grid, hipStream_t st)
 {
-    if (parity) hipLaunchKernelGGL((reset_kernel<Env, true>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((reset_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
+    if (parity) hipLaunchKernelGGL((reset_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((reset_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-// the MFMA actor exists for even state dims and at most 8 actions (nig_set_mlp_policy refuses the others,
-// so a handle of such an env never gets here with a weight stream installed)
+// the MFMA actor exists for even state dims and at most 8 actions (nig_set_mlp_policy refuses the others)
 template <class Env>
 static void launch_mlp(const MlpArgs &q, unsigned grid, hipStream_t st)
 {
@@ -1335,10 +1216,10 @@ static void launch_mlp(const MlpArgs &q, unsigned grid, hipStream_t st)
 }
 
 template <class Env>
-static void launch_step(const StepArgs &a, bool parity, hipStream_t st)
+static void launch_step(const StepArgs &a, bool parity, unsigned grid, hipStream_t st)
 {
-    if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid_for(a.B)), dim3(BLOCK), 0, st, a);
+    if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 template <class Env, bool PAIRED>
@@ -1370,622 +1251,29 @@ static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, 
     }
 }
 
-static void launch_rollout(int env, int out_mode, const RolloutArgs &q, uint32_t t0, unsigned grid, hipStream_t st)
+template <class Env>
+static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
 {
-    NIG_DISPATCH_ENV(env, launch_rollout_env<E>(out_mode, q, t0, grid, st));
+    hipLaunchKernelGGL((rollout_policy_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, q);
 }
 
-static StepArgs base_step_args(const nig_handle *h)
+template <class Env>
+static void launch_fill(float *act, int64_t ld_act, int64_t B, uint64_t env0, uint32_t seed_lo, uint32_t seed_hi, uint32_t t,
+                        unsigned grid, hipStream_t st)
 {
-    const nig_layout &L = h->lay;
-    StepArgs a;
-    memset(&a, 0, sizeof a);
-    a.state = h->state; a.ld_state = (uint32_t)h->ld_state; a.ctr = (uint32_t *)(h->ws + L.off_ctr);
-    a.life_viol = (long long *)(h->ws + L.off_life_viol);
-    a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
-    a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
-    a.ld = (uint32_t)L.ld; a.B = (uint32_t)h->B;
-    a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
-    a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.hflags = h->flags; a.cmask = h->cmask;
-    return a;
+    hipLaunchKernelGGL((fill_actions_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, act, ld_act, B, env0, seed_lo, seed_hi, t);
 }
 
-static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, hipStream_t st)
+template <class Env>
+static const EnvLaunch *env_launch_table()
 {
-    NIG_DISPATCH_ENV(h->env, launch_step<E>(a, parity, st));
+    static const EnvLaunch T = {launch_step<Env>, launch_rollout_env<Env>, launch_policy<Env>,
+                                (Env::S % 2 == 0 && Env::A <= 8) ? launch_mlp<Env> : nullptr,
+                                launch_reset<Env>, launch_fill<Env>};
+    return &T;
 }
 
-extern "C" {
+}  // namespace nig
 
-const char *nig_version(void) { return "nig 0.1.0 (gfx950)"; }
-const char *nig_last_error(void) { return g_err; }
-
-int nig_env_id(const char *name)
-{
-    if (!name) return -1;
-    for (int i = 0; i < NIG_NUM_ENVS; ++i)
-        if (strcmp(name, NAMES[i]) == 0) return i;
-    return -1;
-}
-
-const char *nig_env_name(int env) { return (env >= 0 && env < NIG_NUM_ENVS) ? NAMES[env] : nullptr; }
-
-int nig_env_spec_get(int env, nig_env_spec *out)
-{
-    if (env < 0 || env >= NIG_NUM_ENVS || !out) return fail(NIG_ERR_INVALID, "nig_env_spec_get: bad env id%s");
-    *out = SPECS[env];
-    return NIG_OK;
-}
-
-static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
-
-int nig_layout_query(int env, int64_t batch, uint32_t flags, nig_layout *out)
-{
-    if (env < 0 || env >= NIG_NUM_ENVS || !out) return fail(NIG_ERR_INVALID, "nig_layout_query: bad env id%s");
-    if (batch <= 0) return fail(NIG_ERR_INVALID, "nig_layout_query: batch must be positive%s");
-    nig_layout L;
-    L.batch = batch;
-    L.ld = align_up(batch, 64);
-    int64_t off = 0;
-    L.off_state = off;      off = align_up(off + (int64_t)SPECS[env].state_dim * L.ld * 4, 256);
-    L.off_ctr = off;        off = align_up(off + L.ld * 4, 256);
-    L.off_life_viol = off;  off = align_up(off + L.ld * 8, 256);
-    if (flags & NIG_F_TALLY) {
-        L.off_ep_return = off;  off = align_up(off + L.ld * 8, 256);
-        L.off_tally = off;      off = align_up(off + (int64_t)NIG_T_ROWS * L.ld * 8, 256);
-    } else {
-        L.off_ep_return = -1;
-        L.off_tally = -1;
-    }
-    // tail: reduce scratch + the device-resident launch counter used by plans
-    off = align_up(off + (int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256) + 256 + POLICY_BYTES;
-    L.bytes = off;
-    *out = L;
-    return NIG_OK;
-}
-
-
-int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_index0, int32_t max_episode_steps,
-               double dt, uint32_t flags, void *workspace, nig_handle **out)
-{
-    if (!out) return fail(NIG_ERR_INVALID, "nig_create: out is NULL%s");
-    *out = nullptr;
-    if (env < 0 || env >= NIG_NUM_ENVS) return fail(NIG_ERR_INVALID, "nig_create: unknown env id%s");
-    if (batch <= 0 || batch > NIG_MAX_BATCH) return fail(NIG_ERR_INVALID, "nig_create: batch outside [1, 2^24]%s");
-    if (max_episode_steps < 0 || max_episode_steps > NIG_MAX_EPISODE_STEPS)
-        return fail(NIG_ERR_INVALID, "nig_create: max_episode_steps outside [1, 21845]%s");
-    if (dt < 0.0 || dt != dt) return fail(NIG_ERR_INVALID, "nig_create: bad dt%s");
-    if (SPECS[env].n_constraints > 3 && max_episode_steps > 16383)
-        return fail(NIG_ERR_INVALID, "nig_create: max_episode_steps > 16383 for an env with 4 safety conditions%s");
-    if (env == NIG_ENV_CHEMICAL_REACTOR && dt != 0.0 && dt != 0.1)
-        return fail(NIG_ERR_UNSUPPORTED, "nig_create: ChemicalReactor hard-codes dt=0.1 upstream (chemical_reactor.py:68)%s");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
-        return fail(NIG_ERR_NODEVICE, "nig_create: no HIP device (%s); there is no CPU fallback",
-                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
-    if (device < 0 || device >= ndev) return fail(NIG_ERR_INVALID, "nig_create: device index out of range%s");
-    HIP_TRY(hipSetDevice(device));
-
-    nig_handle *h = new (std::nothrow) nig_handle();
-    if (!h) return fail(NIG_ERR_INVALID, "nig_create: out of host memory%s");
-    h->env = env; h->device = device; h->B = batch; h->seed = seed; h->env0 = env_index0;
-    h->max_steps = max_episode_steps ? max_episode_steps : SPECS[env].max_episode_steps;
-    h->dt = (dt != 0.0) ? dt : SPECS[env].dt;
-    h->flags = flags; h->t = 0; h->cmask = 0xFu;
-    nig_layout_query(env, batch, flags, &h->lay);
-    if (workspace) {
-        if (((uintptr_t)workspace & 255u) != 0) { delete h; return fail(NIG_ERR_INVALID, "nig_create: workspace not 256-byte aligned%s"); }
-        h->ws = (char *)workspace; h->owns_ws = false;
-    } else {
-        void *p = nullptr;
-        hipError_t me = hipMalloc(&p, (size_t)h->lay.bytes);
-        if (me != hipSuccess) { delete h; return fail(NIG_ERR_HIP, "hipMalloc workspace: %s", hipGetErrorString(me)); }
-        h->ws = (char *)p; h->owns_ws = true;
-    }
-    h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
-    h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
-    h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false; h->mlp_stream = nullptr; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0;
-    h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
-    const nig_layout &L = h->lay;
-    hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
-                       (uint32_t *)(h->ws + L.off_ctr), (long long *)(h->ws + L.off_life_viol),
-                       L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr,
-                       L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr, L.ld, L.batch);
-    hipError_t le = hipGetLastError();
-    if (le == hipSuccess) le = hipMemsetAsync(h->ws + L.off_state, 0, (size_t)SPECS[env].state_dim * L.ld * 4, (hipStream_t)0);
-    if (le == hipSuccess) le = hipStreamSynchronize((hipStream_t)0);
-    if (le != hipSuccess) {
-        if (h->owns_ws) (void)hipFree(h->ws);
-        delete h;
-        return fail(NIG_ERR_HIP, "nig_create: workspace init failed: %s", hipGetErrorString(le));
-    }
-    *out = h;
-    return NIG_OK;
-}
-
-int nig_destroy(nig_handle *h)
-{
-    if (!h) return NIG_OK;
-    if (h->mlp_stream) (void)hipFree(h->mlp_stream);
-    if (h->hst_dev) (void)hipFree(h->hst_dev);
-    if (h->hst_pinned) (void)hipHostFree(h->hst_pinned);
-    if (h->owns_ws && h->ws) (void)hipFree(h->ws);
-    delete h;
-    return NIG_OK;
-}
-
-int nig_get_layout(const nig_handle *h, nig_layout *out)
-{
-    if (!h || !out) return fail(NIG_ERR_INVALID, "nig_get_layout: NULL argument%s");
-    *out = h->lay;
-    return NIG_OK;
-}
-
-void *nig_workspace(const nig_handle *h) { return h ? (void *)h->ws : nullptr; }
-
-int nig_get_counter(const nig_handle *h, uint32_t *t)
-{
-    if (!h || !t) return fail(NIG_ERR_INVALID, "nig_get_counter: NULL argument%s");
-    *t = h->t;
-    return NIG_OK;
-}
-
-int nig_bind_state(nig_handle *h, float *state, int64_t ld)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_bind_state: NULL handle%s");
-    if (!state) { h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld; return NIG_OK; }
-    if (ld < h->B || ld > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_bind_state: ld outside [batch, 2^26]%s");
-    if (((uintptr_t)state & 3u) != 0) return fail(NIG_ERR_INVALID, "nig_bind_state: unaligned pointer%s");
-    h->state = state; h->ld_state = ld;
-    return NIG_OK;
-}
-
-int nig_set_constraint_mask(nig_handle *h, uint32_t mask)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_set_constraint_mask: NULL handle%s");
-    h->cmask = mask & 0xFu;
-    return NIG_OK;
-}
-
-int nig_set_counter(nig_handle *h, uint32_t t)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_set_counter: NULL handle%s");
-    h->t = t;
-    return NIG_OK;
-}
-
-int nig_reset(nig_handle *h, const uint8_t *mask, const double *init_noise, int64_t ld_noise, void *stream)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_reset: NULL handle%s");
-    if (init_noise && ld_noise < h->B) return fail(NIG_ERR_INVALID, "nig_reset: ld_noise < batch%s");
-    const nig_layout &L = h->lay;
-    ResetArgs a;
-    a.state = h->state; a.ld_state = h->ld_state; a.ctr = (uint32_t *)(h->ws + L.off_ctr);
-    a.life_viol = (long long *)(h->ws + L.off_life_viol);
-    a.ep_ret = L.off_ep_return >= 0 ? (double *)(h->ws + L.off_ep_return) : nullptr;
-    a.ld = L.ld; a.B = h->B; a.mask = mask; a.noise = init_noise; a.ld_noise = ld_noise;
-    a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32); a.t = h->t;
-    hipStream_t st = (hipStream_t)stream;
-    NIG_DISPATCH_ENV(h->env, launch_reset<E>(a, init_noise != nullptr, st));
-    HIP_TRY(hipGetLastError());
-    return NIG_OK;
-}
-
-int nig_step(nig_handle *h, const float *actions, int64_t ld_act, const double *step_noise, const double *reset_noise,
-             int64_t ld_noise, float *reward_out, double *reward64_out, uint32_t *flags_out, float *final_obs,
-             int64_t ld_obs, void *stream)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_step: NULL handle%s");
-    if (!actions || ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step: actions NULL or ld_act outside [batch, 2^26]%s");
-    const nig_env_spec &sp = SPECS[h->env];
-    const bool autoreset = (h->flags & NIG_F_AUTORESET) != 0;
-    // parity mode = the caller supplies every value the reference's RNG would have drawn
-    const bool parity = (step_noise != nullptr) || (reset_noise != nullptr);
-    if (parity) {
-        if (sp.k_step > 0 && !step_noise) return fail(NIG_ERR_INVALID, "nig_step: parity mode needs step_noise%s");
-        if (autoreset && !reset_noise) return fail(NIG_ERR_INVALID, "nig_step: parity mode with auto-reset needs reset_noise%s");
-        if (ld_noise < h->B || ld_noise > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step: ld_noise outside [batch, 2^26]%s");
-    }
-    if (final_obs && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH)) return fail(NIG_ERR_INVALID, "nig_step: ld_obs outside [batch, 2^26]%s");
-    h->t += 1;
-    StepArgs a = base_step_args(h);
-    a.actions = actions; a.ld_act = (uint32_t)ld_act;
-    a.step_noise = step_noise; a.reset_noise = reset_noise; a.ld_noise = (uint32_t)ld_noise;
-    a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = (uint32_t)ld_obs;
-    a.t_ptr = nullptr; a.t_off = h->t;
-    dispatch_step(h, a, parity, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
-    return NIG_OK;
-}
-
-int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
-                int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride,
-                float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
-{
-    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout: bad argument%s");
-    if (ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout: ld_act outside [batch, 2^26]%s");
-    if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act || slot_stride > 0xffffffffLL)
-        return fail(NIG_ERR_INVALID, "nig_rollout: slot_stride smaller than one [A][ld_act] slot (or >= 2^32)%s");
-    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
-        return fail(NIG_ERR_INVALID, "nig_rollout: out_stride outside {0} U [batch, 2^26]%s");
-    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: n_steps*out_stride >= 2^32%s");
-    const bool obs_aos = obs_out && ld_obs == 0;
-    if (obs_out && !obs_aos && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH || obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs))
-        return fail(NIG_ERR_INVALID, "nig_rollout: bad observation trajectory pitch%s");
-    if (obs_aos && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
-        return fail(NIG_ERR_INVALID, "nig_rollout: row-major trajectory needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
-    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: launch counter would wrap%s");
-    RolloutArgs q;
-    memset(&q, 0, sizeof q);
-    q.s = base_step_args(h);
-    q.s.actions = action_ring; q.s.ld_act = (uint32_t)ld_act;
-    q.s.reward = reward_out; q.s.flags = flags_out;
-    q.s.t_ptr = nullptr; q.s.t_off = h->t;
-    q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
-    q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = obs_aos ? 1 : 0;
-    hipStream_t st = (hipStream_t)stream;
-    if ((reward_out == nullptr) != (flags_out == nullptr))
-        return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
-    if (obs_out && !reward_out)
-        return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
-    const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
-    launch_rollout(h->env, out_mode, q, h->t + 1u, grid_for(h->B), st);
-    HIP_TRY(hipGetLastError());
-    h->t += (uint32_t)n_steps;
-    return NIG_OK;
-}
-
-int nig_set_policy(nig_handle *h, const nig_policy *policy, void *stream)
-{
-    if (!h || !policy) return fail(NIG_ERR_INVALID, "nig_set_policy: NULL argument%s");
-    static_assert(sizeof(nig_policy) <= POLICY_BYTES, "policy struct outgrew its device slot");
-    if (policy->kind != NIG_POLICY_AFFINE && policy->kind != NIG_POLICY_PID)
-        return fail(NIG_ERR_INVALID, "nig_set_policy: unknown policy kind%s");
-    if (!(policy->clip_lo <= policy->clip_hi)) return fail(NIG_ERR_INVALID, "nig_set_policy: clip_lo > clip_hi%s");
-    h->pol_host = *policy;
-    // recompute the non-zero column mask here so a caller cannot get it wrong
-    uint32_t cm = 0;
-    for (int k = 0; k < SPECS[h->env].state_dim; ++k)
-        for (int j = 0; j < SPECS[h->env].action_dim; ++j)
-            if (policy->Wt[k][j] != 0.0f) cm |= (1u << k);
-    h->pol_host.colmask = cm;
-    HIP_TRY(hipMemcpyAsync(h->pol_dev, &h->pol_host, sizeof(nig_policy), hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // pageable source: make the staging copy reusable
-    h->has_policy = true;
-    return NIG_OK;
-}
-
-int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out, int64_t out_stride,
-                       float *obs_out, int64_t obs_step_stride, float *act_out, int64_t ld_act,
-                       int64_t act_step_stride, void *stream)
-{
-    if (!h || n_steps <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_policy: bad argument%s");
-    if (!h->has_policy) return fail(NIG_ERR_INVALID, "nig_rollout_policy: no policy installed (nig_set_policy)%s");
-    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
-        return fail(NIG_ERR_INVALID, "nig_rollout_policy: out_stride outside {0} U [batch, 2^26]%s");
-    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_policy: n_steps*out_stride >= 2^32%s");
-    if (obs_out && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
-        return fail(NIG_ERR_INVALID, "nig_rollout_policy: obs_out needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
-    if (act_out && (ld_act < h->B || ld_act > NIG_MAX_PITCH || act_step_stride < (int64_t)SPECS[h->env].action_dim * ld_act))
-        return fail(NIG_ERR_INVALID, "nig_rollout_policy: bad action trajectory pitch%s");
-    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_policy: launch counter would wrap%s");
-    PolicyArgs q;
-    memset(&q, 0, sizeof q);
-    q.s = base_step_args(h);
-    q.s.reward = reward_out; q.s.flags = flags_out;
-    q.s.t_ptr = nullptr; q.s.t_off = h->t;
-    q.pol = h->pol_dev; q.n_steps = n_steps; q.out_stride = (uint32_t)out_stride;
-    q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
-    q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
-    hipStream_t st = (hipStream_t)stream;
-    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((rollout_policy_kernel<E>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, q));
-    HIP_TRY(hipGetLastError());
-    h->t += (uint32_t)n_steps;
-    return NIG_OK;
-}
-
-// Row of a 32x32 MFMA result tile held in register t by lane half hf (MI355X_MICROARCH / guide section 3).
-static inline int mfma_row(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
-
-int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const float *b1, const float *W2, const float *b2,
-                       const float *W3, const float *b3, void *stream)
-{
-    if (!h || !W1 || !b1 || !W2 || !b2 || !W3 || !b3) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: NULL argument%s");
-    if (hidden != MLP_H) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: hidden must be 256 (agents/networks.py default)%s");
-    const int S = SPECS[h->env].state_dim, A = SPECS[h->env].action_dim, H = MLP_H;
-    if (S % 2 != 0 || A > 8) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: env shape not supported%s");
-    const int nrec = mlp_records(S);
-    float *host = (float *)calloc((size_t)nrec * 64, sizeof(float));
-    if (!host) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: out of host memory%s");
-    // Build the operand stream in exactly the order rollout_mlp_kernel consumes it.  Record = 64 floats;
-    // lane l = (i = l & 31, hf = l >> 5) holds W[k(hf)][32*tile + i].
-    int r = 0;
-    for (int m = 0; m < MLP_MT; ++m) {                      // layer 1, natural k order: k = 2*ks + hf
-        for (int ks = 0; ks < S / 2; ++ks, ++r)
-            for (int l = 0; l < 64; ++l) host[(size_t)r * 64 + l] = W1[(size_t)(2 * ks + (l >> 5)) * H + 32 * m + (l & 31)];
-        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b1[32 * m + l];
-        ++r;
-    }
-    for (int m2 = 0; m2 < MLP_MT; ++m2) {
-        for (int kt = 0; kt < MLP_MT; ++kt)                   // layer 2: k follows the accumulator register order of h1
-            for (int t = 0; t < 16; ++t, ++r)
-                for (int l = 0; l < 64; ++l)
-                    host[(size_t)r * 64 + l] = W2[(size_t)(32 * kt + mfma_row(t, l >> 5)) * H + 32 * m2 + (l & 31)];
-        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b2[32 * m2 + l];
-        ++r;
-        for (int t = 0; t < 16; ++t, ++r)                     // head: rows i >= A are zero
-            for (int l = 0; l < 64; ++l)
-                if ((l & 31) < A) host[(size_t)r * 64 + l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
-    }
-    for (int l = 0; l < A; ++l) host[(size_t)r * 64 + l] = b3[l];
-    ++r;
-    if (r != nrec) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
-    hipError_t e = hipSuccess;
-    // the kernel prefetches up to 29 records past the end (values unused): keep them inside the allocation
-    if (!h->mlp_stream) {
-        const size_t bytes = (size_t)(mlp_records(32) + 32) * 64 * sizeof(float);
-        e = hipMalloc((void **)&h->mlp_stream, bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(h->mlp_stream, 0, bytes, (hipStream_t)stream);
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)nrec * 64 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    free(host);
-    if (e != hipSuccess) return fail(NIG_ERR_HIP, "nig_set_mlp_policy: %s", hipGetErrorString(e));
-    return NIG_OK;
-}
-
-int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t *flags_out, int64_t out_stride,
-                    float *obs_out, int64_t obs_step_stride, float *act_out, int64_t ld_act, int64_t act_step_stride,
-                    void *stream)
-{
-    if (!h || n_steps <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: bad argument%s");
-    if (!h->mlp_stream) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: no actor installed (nig_set_mlp_policy)%s");
-    if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
-        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: out_stride outside {0} U [batch, 2^26]%s");
-    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: n_steps*out_stride >= 2^32%s");
-    if (obs_out && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
-        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: obs_out needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
-    if (act_out && (ld_act < h->B || ld_act > NIG_MAX_PITCH || act_step_stride < (int64_t)SPECS[h->env].action_dim * ld_act))
-        return fail(NIG_ERR_INVALID, "nig_rollout_mlp: bad action trajectory pitch%s");
-    if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: launch counter would wrap%s");
-    MlpArgs q;
-    memset(&q, 0, sizeof q);
-    q.s = base_step_args(h);
-    q.s.reward = reward_out; q.s.flags = flags_out;
-    q.s.t_ptr = nullptr; q.s.t_off = h->t;
-    q.wstream = h->mlp_stream; q.n_steps = n_steps; q.out_stride = (uint32_t)out_stride;
-    q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
-    q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((h->B + BLOCK / 2 - 1) / (BLOCK / 2));     // 32 envs per wave, 128 per block
-    NIG_DISPATCH_ENV(h->env, launch_mlp<E>(q, grid, st));
-    HIP_TRY(hipGetLastError());
-    h->t += (uint32_t)n_steps;
-    return NIG_OK;
-}
-
-// ---- host-buffer entry points (small batches) -------------------------------------------------
-// staging layout (same on host and device): [actions f32 A*B][noise f64 K*B] | [state f32 S*B][reward64 f64 B][flags u32 B]
-// (uploads = the first part, downloads = the second part: one memcpy each way)
-struct HostStage { size_t off_act, off_noise, off_state, off_rew, off_flags, bytes; };
-
-static HostStage host_stage_layout(const nig_handle *h)
-{
-    const nig_env_spec &sp = SPECS[h->env];
-    const size_t B = (size_t)h->B;
-    const size_t K = (size_t)(sp.k_step > sp.k_reset ? sp.k_step : sp.k_reset);
-    HostStage L;
-    L.off_act = 0;
-    L.off_noise = (size_t)align_up((int64_t)(sp.action_dim * B * 4), 256);
-    L.off_state = L.off_noise + (size_t)align_up((int64_t)(K * B * 8), 256);
-    L.off_rew = L.off_state + (size_t)align_up((int64_t)(sp.state_dim * B * 4), 256);
-    L.off_flags = L.off_rew + (size_t)align_up((int64_t)(B * 8), 256);
-    L.bytes = L.off_flags + (size_t)align_up((int64_t)(B * 4), 256);
-    return L;
-}
-
-constexpr int64_t HOST_ZERO_COPY_MAX = 1024;   // lanes up to which the host-buffer entry points skip the staging copies
-
-static int host_stage_ensure(nig_handle *h, const HostStage &L)
-{
-    if (h->hst_pinned && h->hst_bytes >= L.bytes) return NIG_OK;
-    if (h->B > 65536) return fail(NIG_ERR_UNSUPPORTED, "host-buffer entry points are for small batches (<= 65536 lanes)%s");
-    if (h->hst_dev) { (void)hipFree(h->hst_dev); h->hst_dev = nullptr; }
-    if (h->hst_pinned) { (void)hipHostFree(h->hst_pinned); h->hst_pinned = nullptr; }
-    HIP_TRY(hipHostMalloc((void **)&h->hst_pinned, L.bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&h->hst_dev, L.bytes));
-    h->hst_bytes = L.bytes;
-    return NIG_OK;
-}
-
-int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, void *stream)
-{
-    if (!h || !state_out) return fail(NIG_ERR_INVALID, "nig_reset_host: NULL argument%s");
-    const nig_env_spec &sp = SPECS[h->env];
-    const HostStage L = host_stage_layout(h);
-    int rc = host_stage_ensure(h, L);
-    if (rc != NIG_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t B = (size_t)h->B;
-    const double *dn = nullptr;
-    if (init_noise && sp.k_reset > 0) {
-        memcpy(h->hst_pinned + L.off_noise, init_noise, (size_t)sp.k_reset * B * 8);
-        HIP_TRY(hipMemcpyAsync(h->hst_dev + L.off_noise, h->hst_pinned + L.off_noise, (size_t)sp.k_reset * B * 8, hipMemcpyHostToDevice, st));
-        dn = (const double *)(h->hst_dev + L.off_noise);
-    }
-    rc = nig_reset(h, nullptr, dn, (int64_t)B, stream);
-    if (rc != NIG_OK) return rc;
-    // gather the rows (ld apart on the device) into the contiguous staging image, then ONE download
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
-                       (float *)(h->hst_dev + L.off_state), (int64_t)B, sp.state_dim, h->B);
-    HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, (size_t)sp.state_dim * B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);
-    return NIG_OK;
-}
-
-int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out, double *reward64_out,
-                  uint32_t *flags_out, void *stream)
-{
-    if (!h || !actions || !state_out || !reward64_out || !flags_out) return fail(NIG_ERR_INVALID, "nig_step_host: NULL argument%s");
-    const nig_env_spec &sp = SPECS[h->env];
-    const HostStage L = host_stage_layout(h);
-    int rc = host_stage_ensure(h, L);
-    if (rc != NIG_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t B = (size_t)h->B;
-    memcpy(h->hst_pinned + L.off_act, actions, (size_t)sp.action_dim * B * 4);
-    size_t up = (size_t)sp.action_dim * B * 4;
-    const double *dn = nullptr;
-    if (step_noise && sp.k_step > 0) {
-        memcpy(h->hst_pinned + L.off_noise, step_noise, (size_t)sp.k_step * B * 8);
-        up = L.off_noise + (size_t)sp.k_step * B * 8;          // one contiguous upload covers both
-        dn = (const double *)(h->hst_dev + L.off_noise);
-    }
-    // Small batches (the single-env drop-in class is B = 1): the kernels read the actions / noise from, and
-    // write state / reward / flags to, the pinned staging buffer itself -- hipHostMalloc memory is mapped
-    // and coherent, a few hundred bytes over PCIe cost less than two copy commands -- so a step is two
-    // kernel launches and one stream sync.  Larger batches keep one upload + one download.
-    const bool zero_copy = h->B <= HOST_ZERO_COPY_MAX;
-    char *io = zero_copy ? h->hst_pinned : h->hst_dev;
-    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
-    if (dn) dn = (const double *)(io + L.off_noise);
-    rc = nig_step(h, (const float *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
-                  (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream);
-    if (rc != NIG_OK) return rc;
-    // state rows gathered next to reward64 and flags: one download for everything the call returns
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
-                       (float *)(io + L.off_state), (int64_t)B, sp.state_dim, h->B);
-    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, L.bytes - L.off_state, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);
-    memcpy(reward64_out, h->hst_pinned + L.off_rew, B * 8);
-    memcpy(flags_out, h->hst_pinned + L.off_flags, B * 4);
-    return NIG_OK;
-}
-
-int nig_plan_create(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
-                    int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride, nig_plan **out)
-{
-    if (!out) return fail(NIG_ERR_INVALID, "nig_plan_create: out is NULL%s");
-    *out = nullptr;
-    if (!h || !action_ring || n_steps <= 0 || ring_len <= 0 || ld_act < h->B || ld_act > NIG_MAX_PITCH)
-        return fail(NIG_ERR_INVALID, "nig_plan_create: bad argument%s");
-    if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act)
-        return fail(NIG_ERR_INVALID, "nig_plan_create: slot_stride smaller than one [A][ld_act] slot%s");
-    if (out_stride != 0 && out_stride < h->B) return fail(NIG_ERR_INVALID, "nig_plan_create: out_stride < batch%s");
-    nig_plan *p = new (std::nothrow) nig_plan();
-    if (!p) return fail(NIG_ERR_INVALID, "nig_plan_create: out of host memory%s");
-    p->h = h; p->n_steps = n_steps; p->graph = nullptr; p->exec = nullptr;
-    HIP_TRY(hipSetDevice(h->device));
-    hipStream_t cs = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete p; return fail(NIG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
-    if (e == hipSuccess) {
-        for (int k = 0; k < n_steps; ++k) {
-            StepArgs a = base_step_args(h);
-            const int slot = k % ring_len;
-            a.actions = action_ring + (int64_t)slot * slot_stride; a.ld_act = (uint32_t)ld_act;
-            a.reward = reward_out ? reward_out + (int64_t)slot * out_stride : nullptr;
-            a.flags = flags_out ? flags_out + (int64_t)slot * out_stride : nullptr;
-            a.t_ptr = h->t_dev; a.t_off = (uint32_t)(k + 1);
-            dispatch_step(h, a, false, cs);
-        }
-        e = hipStreamEndCapture(cs, &p->graph);
-    }
-    if (e == hipSuccess) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
-    (void)hipStreamDestroy(cs);
-    if (e != hipSuccess) {
-        if (p->graph) (void)hipGraphDestroy(p->graph);
-        delete p;
-        return fail(NIG_ERR_HIP, "nig_plan_create: graph capture failed: %s", hipGetErrorString(e));
-    }
-    *out = p;
-    return NIG_OK;
-}
-
-int nig_plan_launch(nig_plan *p, void *stream)
-{
-    if (!p) return fail(NIG_ERR_INVALID, "nig_plan_launch: NULL plan%s");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, p->h->t_dev, p->h->t);
-    HIP_TRY(hipGraphLaunch(p->exec, st));
-    p->h->t += (uint32_t)p->n_steps;
-    return NIG_OK;
-}
-
-int nig_plan_destroy(nig_plan *p)
-{
-    if (!p) return NIG_OK;
-    if (p->exec) (void)hipGraphExecDestroy(p->exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
-    delete p;
-    return NIG_OK;
-}
-
-int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream)
-{
-    if (!h || !actions || ld_act < h->B) return fail(NIG_ERR_INVALID, "nig_fill_actions: bad argument%s");
-    hipStream_t st = (hipStream_t)stream;
-    const uint32_t lo = (uint32_t)h->seed, hi = (uint32_t)(h->seed >> 32);
-    NIG_DISPATCH_ENV(h->env, hipLaunchKernelGGL((fill_actions_kernel<E>), dim3(grid_for(h->B)), dim3(BLOCK), 0, st, actions, ld_act, h->B, h->env0, lo, hi, t));
-    HIP_TRY(hipGetLastError());
-    return NIG_OK;
-}
-
-int nig_set_state(nig_handle *h, const float *state, int64_t ld, const uint32_t *ctr, void *stream)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_set_state: NULL handle%s");
-    hipStream_t st = (hipStream_t)stream;
-    const nig_layout &L = h->lay;
-    if (state) {
-        if (ld < h->B) return fail(NIG_ERR_INVALID, "nig_set_state: ld < batch%s");
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, state, ld,
-                           h->state, h->ld_state, SPECS[h->env].state_dim, h->B);
-        HIP_TRY(hipGetLastError());
-    }
-    if (ctr) HIP_TRY(hipMemcpyAsync(h->ws + L.off_ctr, ctr, (size_t)h->B * 4, hipMemcpyDeviceToDevice, st));
-    return NIG_OK;
-}
-
-int nig_get_state(nig_handle *h, float *state, int64_t ld, uint32_t *ctr, void *stream)
-{
-    if (!h) return fail(NIG_ERR_INVALID, "nig_get_state: NULL handle%s");
-    hipStream_t st = (hipStream_t)stream;
-    const nig_layout &L = h->lay;
-    if (state) {
-        if (ld < h->B) return fail(NIG_ERR_INVALID, "nig_get_state: ld < batch%s");
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st,
-                           (const float *)h->state, h->ld_state, state, ld, SPECS[h->env].state_dim, h->B);
-        HIP_TRY(hipGetLastError());
-    }
-    if (ctr) HIP_TRY(hipMemcpyAsync(ctr, h->ws + L.off_ctr, (size_t)h->B * 4, hipMemcpyDeviceToDevice, st));
-    return NIG_OK;
-}
-
-int nig_get_safety_metrics(nig_handle *h, const uint32_t *flags, int32_t *out, int64_t ld_out, void *stream)
-{
-    if (!h || !flags || !out || ld_out < h->B) return fail(NIG_ERR_INVALID, "nig_get_safety_metrics: bad argument%s");
-    hipLaunchKernelGGL(safety_metrics_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, (hipStream_t)stream, flags, out, ld_out, h->B);
-    HIP_TRY(hipGetLastError());
-    return NIG_OK;
-}
-
-int nig_reduce_tally(nig_handle *h, double *partial_out, void *stream)
-{
-    if (!h || !partial_out) return fail(NIG_ERR_INVALID, "nig_reduce_tally: NULL argument%s");
-    if (h->lay.off_tally < 0) return fail(NIG_ERR_INVALID, "nig_reduce_tally: handle created without NIG_F_TALLY%s");
-    hipStream_t st = (hipStream_t)stream;
-    int nblk = (int)((h->B + BLOCK - 1) / BLOCK);
-    if (nblk > REDUCE_BLOCKS) nblk = REDUCE_BLOCKS;
-    hipLaunchKernelGGL(reduce_tally_stage1, dim3(nblk), dim3(BLOCK), 0, st, (const double *)(h->ws + h->lay.off_tally),
-                       h->lay.ld, h->B, h->scratch);
-    hipLaunchKernelGGL(reduce_tally_stage2, dim3(1), dim3(64), 0, st, (const double *)h->scratch, nblk, partial_out);
-    HIP_TRY(hipGetLastError());
-    return NIG_OK;
-}
-
-}  // extern "C"
+#define NIG_DEFINE_ENV_LAUNCH(EnvType, fn_name) \
+    const nig::EnvLaunch *fn_name() { return nig::env_launch_table<nig::EnvType>(); }

@@ -37,16 +37,21 @@ def combine_partials(partials: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def all_reduce_partial(partial: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather every rank's partial vector and combine identically everywhere."""
+def all_gather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
+    """Every rank's partial vector, [world, T_ROWS], in rank order (identical on every rank)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return combine_partials(partial.reshape(1, -1))
-    world = dist.get_world_size(group)
     flat = partial.contiguous().reshape(-1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat.reshape(1, -1)
+    world = dist.get_world_size(group)
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat, group=group)          # ncclAllGather (RCCL) / gloo allgather
-    return combine_partials(torch.stack(gathered))
+    return torch.stack(gathered)
+
+
+def all_reduce_partial(partial: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather every rank's partial vector and combine identically everywhere."""
+    return combine_partials(all_gather_partials(partial, group))
 
 
 def metrics_from_partial(p, n_episodes: Optional[int] = None) -> Dict[str, float]:
@@ -61,7 +66,6 @@ def metrics_from_partial(p, n_episodes: Optional[int] = None) -> Dict[str, float
     lmean = p[_lib.T_LEN_SUM] / n
     rvar = max(p[_lib.T_RET_SQ] / n - rmean * rmean, 0.0)     # population std, np.std default
     lvar = max(p[_lib.T_LEN_SQ] / n - lmean * lmean, 0.0)
-    steps = p[_lib.T_LEN_SUM]
     viol = int(round(p[_lib.T_VIOL]))
     succ = int(round(p[_lib.T_SUCCESS]))
     return {
@@ -71,7 +75,9 @@ def metrics_from_partial(p, n_episodes: Optional[int] = None) -> Dict[str, float
         "safety_violations": viol, "safety_violations_per_episode": viol / n_episodes,
         "critical_violations": int(round(p[_lib.T_CRIT])),
         "emergency_shutdowns": int(round(p[_lib.T_SHUTDOWN])),
-        # mean over steps of satisfied/total with total == 3 (utils.py:109,144-147)
-        "constraint_satisfaction_rate": float((3.0 * steps - p[_lib.T_VIOL]) / (3.0 * steps)) if steps > 0 else 1.0,
+        # mean over steps of constraints_satisfied / total_constraints (utils.py:109,144-147); the tally carries
+        # both sums, so any number of enabled constraints (4 for AdvancedChemicalReactor, fewer after
+        # remove_safety_constraint, 0 -> every step's rate is 1.0) comes out right
+        "constraint_satisfaction_rate": float(p[_lib.T_SATISFIED] / p[_lib.T_CONSTRAINTS]) if p[_lib.T_CONSTRAINTS] > 0 else 1.0,
         "successful_episodes": succ, "success_rate": succ / n_episodes,
     }

@@ -140,7 +140,9 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
         mask[:k] = 1
         env.ctr.fill_(_lib.CTR_DONE)
         env.reset(mask=mask)
-        (env.rollout_mlp if fused_mlp else env.rollout_policy)(env.max_episode_steps)
+        # one step more than the cap: the Advanced envs truncate on the step AFTER the cap
+        # (advanced_chemical_reactor.py:351 tests episode_step before its increment); finished lanes are frozen
+        (env.rollout_mlp if fused_mlp else env.rollout_policy)(env.max_episode_steps + 1)
         remaining -= k
     while remaining > 0:
         k = min(B, remaining)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csvs into per-launch HBM bytes.
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csvs into HBM bytes per launch and per env-step.
 
 Calibration (MI355X_MICROARCH.md "HBM"): on gfx950 FETCH_SIZE is exact only for some access
 widths (it reads 1/2 for 16 B/lane streams) and "other access widths are uncalibrated", so the
@@ -28,7 +28,8 @@ def main():
     env = args[args.index("--env") + 1] if "--env" in args else "cr"
     S = {"cr": 12, "pg": 32, "ra": 24}[env]
     B = int(args[args.index("--batch") + 1]) if "--batch" in args else {"cr": 65536, "pg": 262144, "ra": 262144}[env]
-    ld = (B + 63) // 64 * 64
+    P = int(args[args.index("--plan-steps") + 1]) if "--plan-steps" in args else 250
+    mode = args[args.index("--mode") + 1] if "--mode" in args else "rollout"
     res = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         per = load(os.path.join(out, f"{tag}_{ctr}.csv"))
@@ -46,8 +47,12 @@ def main():
     summary = {}
     for k, d in res.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d and d["FETCH_SIZE"]["bytes_per_launch"] is not None:
-            summary[k] = {"hbm_bytes_per_launch": d["FETCH_SIZE"]["bytes_per_launch"] + d["WRITE_SIZE"]["bytes_per_launch"],
-                          "detail": d}
+            per_launch = d["FETCH_SIZE"]["bytes_per_launch"] + d["WRITE_SIZE"]["bytes_per_launch"]
+            env_steps = B * (P if "rollout_kernel" in k else 1)          # env-steps one kernel launch processes
+            summary[k] = {"hbm_bytes_per_env_step": per_launch / env_steps, "plan_steps": P, "mode": mode,
+                          "env_steps_per_launch": env_steps, "hbm_bytes_per_launch": per_launch,
+                          "fetch_bytes": d["FETCH_SIZE"]["bytes_per_launch"], "write_bytes": d["WRITE_SIZE"]["bytes_per_launch"],
+                          "kernel": k, "detail": d}
     path = os.path.join(out, f"traffic_{tag}.json")
     json.dump(summary, open(path, "w"), indent=1)
     print(json.dumps(summary, indent=1))

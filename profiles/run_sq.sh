@@ -5,6 +5,9 @@ tag=$1; shift
 out=gpurun_out/sq_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# build first: the profiled process must never spawn the compiler (NIG_NO_AUTOBUILD makes a stale library an error)
+python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
+export NIG_NO_AUTOBUILD=1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api "$@" > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'

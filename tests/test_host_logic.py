@@ -11,7 +11,7 @@ import torch
 from conftest import KEYS, ROOT, load_golden, result_of
 
 
-def _tally_from_episodes(ret, length, viol, crit, shut):
+def _tally_from_episodes(ret, length, viol, crit, shut, n_constraints=3):
     import neorl_industrial_gym_amd as ni
     T = ni._lib
     p = np.zeros(T.T_ROWS)
@@ -20,7 +20,27 @@ def _tally_from_episodes(ret, length, viol, crit, shut):
     p[T.T_LEN_SUM] = length.sum(); p[T.T_LEN_SQ] = (length.astype(np.float64) ** 2).sum()
     p[T.T_VIOL] = viol.sum(); p[T.T_CRIT] = crit.sum(); p[T.T_SHUTDOWN] = shut.sum()
     p[T.T_SUCCESS] = (ret > 0).sum()
+    p[T.T_CONSTRAINTS] = n_constraints * length.sum()
+    p[T.T_SATISFIED] = n_constraints * length.sum() - viol.sum()
     return p
+
+
+@pytest.mark.parametrize("n_constraints", [0, 2, 3, 4])
+def test_constraint_satisfaction_rate_for_any_constraint_count(n_constraints):
+    """utils.py:109,144-147: the mean over steps of satisfied/total -- with 4 conditions
+    (AdvancedChemicalReactor), after remove_safety_constraint (2), and with none left (every step 1.0)."""
+    from neorl_industrial_gym_amd.core import SafetyMetrics
+    from neorl_industrial_gym_amd.parallel import metrics_from_partial
+    rng = np.random.default_rng(7)
+    length = rng.integers(1, 40, size=25)
+    per_step = [rng.integers(0, n_constraints + 1, size=n) for n in length]      # violations of every step
+    viol = np.array([v.sum() for v in per_step])
+    rates = [SafetyMetrics(n_constraints - int(x), n_constraints, int(x), 0, 0.0).satisfaction_rate
+             for v in per_step for x in v]
+    ret = rng.normal(size=25)
+    p = _tally_from_episodes(ret, length, viol, np.zeros(25), np.zeros(25), n_constraints)
+    got = metrics_from_partial(p, 25)
+    assert got["constraint_satisfaction_rate"] == pytest.approx(np.mean(rates), rel=1e-12)
 
 
 def test_shard_range_partitions_exactly():
