@@ -194,8 +194,10 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         uint32_t h0, l0, h1, l1;
         mulhilo32(0xD2511F53u, c0, h0, l0);
         mulhilo32(0xCD9E8D57u, c2, h1, l1);
-        const uint32_t n0 = h1 ^ c1 ^ k0;
-        const uint32_t n2 = h0 ^ c3 ^ k1;
+        // three-input xor in ONE instruction (gfx950 v_bitop3_b32, truth table 0x96): the kernels are bound by
+        // VALU issue and a Philox block was 20 wide multiplies + 40 xors
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96);
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -224,15 +226,15 @@ __device__ const float4 NIG_PROBIT[768] = {
 };
 
 // In two halves so a kernel can put other work between the LDS read and its use.
-struct ProbitFetch { float4 c; float t; uint32_t v; };
+struct ProbitFetch { float4 c; float t; uint32_t word; };
 
 __device__ __forceinline__ ProbitFetch probit_fetch(uint32_t word, const float4 *tab)
 {
     ProbitFetch f;
-    f.v = word >> 8;
-    const float x = (float)(f.v & 0x7FFFFFu) + 0.5f;         // exact
+    f.word = word;
+    const float x = (float)__builtin_amdgcn_ubfe(word, 8, 23) + 0.5f;   // m + 1/2, exact (one bit-field extract)
     const uint32_t b = f32_bits(x);
-    f.c = tab[(b >> 18) - (126u << 5)];
+    f.c = tab[__builtin_amdgcn_ubfe(b, 18, 13) - (126u << 5)];
     f.t = (float)(b & 0x3FFFFu) * (1.0f / 262144.0f);        // exact
     return f;
 }
@@ -242,7 +244,9 @@ __device__ __forceinline__ float probit_eval(const ProbitFetch &f)
     float z = __builtin_fmaf(f.c.w, f.t, f.c.z);           // Horner in three fused steps (the generator is this
     z = __builtin_fmaf(z, f.t, f.c.y);                     // build's own spec; the CPU restatement fuses too)
     z = __builtin_fmaf(z, f.t, f.c.x);
-    return (f.v & 0x800000u) ? -z : z;
+    // sign = bit 31 of the word: z ^ (word & 0x80000000) in one v_bitop3_b32 (truth table (a & b) ^ c = 0x6a),
+    // the same bits as "bit set ? -z : z"
+    return bits_f32(__builtin_amdgcn_bitop3_b32(f.word, 0x80000000u, f32_bits(z), 0x6a));
 }
 
 __device__ __forceinline__ float probit_normal(uint32_t word, const float4 *tab)
@@ -254,20 +258,47 @@ __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * (1.
 
 __device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
 
-// N standard normals of stream `stream` into z[0..N): one word each, four per Philox block
+// N standard normals of stream `stream` into z[0..N): one word each, four per Philox block.
+// Many normals (PowerGrid: 23 per step): software-pipelined by hand -- the table reads of block j+1 are issued
+// (behind its ten Philox rounds) before the cubics of block j run, and every finished normal is pinned with an
+// empty asm so the evaluation cannot be deferred.  Left alone, hipcc issues the reads block by block but keeps ALL
+// coefficient quadruples (4 VGPRs per normal: 92 for PowerGrid) alive until one evaluation burst at the end, which
+// pushed the fused PowerGrid rollout into scratch spills.
 template <int N>
 __device__ __forceinline__ void gen_normals(const RngKey &k, uint32_t stream, float (&z)[N])
 {
+    constexpr int NB = (N + 3) / 4;
+    if constexpr (N > 8) {
+        ProbitFetch f[2][4];
+        auto fetch = [&](int j, ProbitFetch (&g)[4]) __attribute__((always_inline)) {
+            const u32x4 x = k.block(stream + (uint32_t)j);
+            g[0] = probit_fetch(x.x, k.tab);
+            if (4 * j + 1 < N) g[1] = probit_fetch(x.y, k.tab);
+            if (4 * j + 2 < N) g[2] = probit_fetch(x.z, k.tab);
+            if (4 * j + 3 < N) g[3] = probit_fetch(x.w, k.tab);
+        };
+        fetch(0, f[0]);
 #pragma unroll
-    for (int j = 0; 4 * j < N; ++j) {
-        const u32x4 x = k.block(stream + (uint32_t)j);
-        if (4 * j + 0 < N) z[4 * j + 0] = probit_normal(x.x, k.tab);
-        if (4 * j + 1 < N) z[4 * j + 1] = probit_normal(x.y, k.tab);
-        if (4 * j + 2 < N) z[4 * j + 2] = probit_normal(x.z, k.tab);
-        if (4 * j + 3 < N) z[4 * j + 3] = probit_normal(x.w, k.tab);
-        // one Philox block (4 table reads = 16 VGPRs of coefficients) at a time: left alone, hipcc issues
-        // the reads of all 23 PowerGrid normals up front and the kernel balloons to 186 VGPRs
-        if (N > 8) __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NB; ++j) {
+            if (j + 1 < NB) fetch(j + 1, f[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * j + q < N) {
+                    z[4 * j + q] = probit_eval(f[j & 1][q]);
+                    asm volatile("" : "+v"(z[4 * j + q]));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const u32x4 x = k.block(stream + (uint32_t)j);
+            if (4 * j + 0 < N) z[4 * j + 0] = probit_normal(x.x, k.tab);
+            if (4 * j + 1 < N) z[4 * j + 1] = probit_normal(x.y, k.tab);
+            if (4 * j + 2 < N) z[4 * j + 2] = probit_normal(x.z, k.tab);
+            if (4 * j + 3 < N) z[4 * j + 3] = probit_normal(x.w, k.tab);
+        }
     }
 }
 

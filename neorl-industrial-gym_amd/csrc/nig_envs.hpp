@@ -10,6 +10,8 @@
 // contiguous elements is the pairwise tree.  The translation unit is compiled with
 // -ffp-contract=off so a*b+c is two roundings, as in NumPy.
 #pragma once
+#include <type_traits>
+
 #include "nig_detmath.hpp"
 
 namespace nig {
@@ -29,6 +31,9 @@ __device__ __forceinline__ T sum8(const T (&x)[8])
 // ChemicalReactor-v0  (environments/chemical_reactor.py), S=12 A=3, all float32
 // =================================================================================
 struct ChemicalReactor {
+    static constexpr bool COOP_RESET = false;
+    static constexpr int RESET_ROWS = 1;
+    using fast_noise_t = double;
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
@@ -168,10 +173,20 @@ struct ChemicalReactor {
 // =================================================================================
 struct PowerGrid {
     static constexpr int ID = 1, S = 32, A = 8, KS = 23, KR = 31, MAX_STEPS = 1000;
-    static constexpr bool COMPACT_RESET = true;    // ~18 % of lanes finish per step (episodes of ~6 steps)
+    // ~18 % of lanes finish per step (episodes of ~6 steps): ~11 lanes of every wave reset in every step.
+    // COOP_RESET: a wave produces the initial states of its finishing lanes cooperatively, one work item =
+    // (lane, generator block) -> 4 state rows, through a wave-private LDS image -- no block barrier, and
+    // ~70 % lane utilisation instead of a whole wave running the 8-block reset path for a few lanes.
+    static constexpr bool COMPACT_RESET = false, COOP_RESET = true;
+    static constexpr int RESET_ITEMS_LOG2 = 3, RESET_ROWS = S;   // 8 generator blocks per reset: 6 of normals, 2 of uniforms
     static constexpr bool SHARED_STEP_BLOCK = false;
+    // Fast-mode step noise stays float32 (sd * z is a float32 product): (float)((double)s + (double)n32) is the
+    // correctly rounded float32 sum s + n32 for ANY two floats (exact in double when the exponents are within
+    // 28 of each other; beyond that both roundings return s), so the reference's fp64 add of :136-144 needs no
+    // fp64 instruction when the noise is float32-valued.  Parity mode (injected fp64 draws) keeps the fp64 adds.
+    using fast_noise_t = float;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
-    static constexpr int STEP_WAVES = 2;          // 23 fp64 noise values + 2x32 state registers: ~184 VGPRs
+    static constexpr int STEP_WAVES = 3;          // float32 fast-mode noise: ~115 VGPRs; the 32-row reset image allows 3 blocks per CU
     static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }
@@ -217,17 +232,53 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < 7; ++i) n[24 + i] = 0.0 + 10.0 * (double)z[16 + i];
     }
+    __device__ static void draw_step(const RngKey &k, float (&n)[KS])
+    {
+        gen_normals<KS>(k, STREAM_STEP, n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) n[i] = 0.005f * n[i];                // :136 (float32 product, see ChemicalReactor); :140 has sd 1.0
+#pragma unroll
+        for (int i = 0; i < 7; ++i) n[16 + i] = 2.0f * n[16 + i];        // :144
+    }
     __device__ static void draw_step(const RngKey &k, double (&n)[KS])
     {
         float z[KS];
-        gen_normals<KS>(k, STREAM_STEP, z);
+        draw_step(k, z);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            n[i] = (double)(0.005f * z[i]);                              // :136 (float32 product, see ChemicalReactor)
-            n[8 + i] = (double)z[8 + i];                                 // :140 (sd 1.0)
+        for (int i = 0; i < KS; ++i) n[i] = (double)z[i];
+    }
+    // One work item of a cooperative reset: generator block `blk` of the lane with key `k` -> the four state
+    // rows its words feed, stored into column `col` (= img + owner lane) of a [RESET_ROWS][64] image.  Same values,
+    // operation by operation, as draw_init + init.  Blocks 0-5: normals z[4 blk + q] (V, gen, line flows);
+    // blocks 6-7: uniforms u[4 (blk - 6) + q] (loads).  Block 0 also clears row 0 (freq_dev).
+    // (A two-phase form with a 16-row image was tried: the rows read back in phase 0 stay live across phase 1's
+    // items and pushed the rollout kernel into scratch spills: -13 %.)
+    __device__ static void reset_item(const RngKey &k, uint32_t blk, float *col)
+    {
+        const bool uni = blk >= 6u;
+        const u32x4 x = k.block(STREAM_RESET + (uni ? 10u + blk : blk));     // uniforms: STREAM_RESET + 16 + (blk - 6)
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        const bool hi = (blk & 1u) != 0;                                     // second half of an 8-vector
+        if (!uni) {
+            // value = (float)(off + (0.0 + sd * z)): V 1.0 / 0.01 (:98), gen base_load / 2.0 (:101), flows (none) / 10.0 (:108)
+            const double sd = blk < 2u ? 0.01 : (blk < 4u ? 2.0 : 10.0);
+            const uint32_t row0 = (blk < 4u ? 1u : 9u) + 4u * blk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double off = blk < 2u ? 1.0 : (blk < 4u ? (hi ? base_load(4 + q) : base_load(q)) : 0.0);
+                const double d = 0.0 + sd * (double)probit_normal(w[q], k.tab);
+                const float v = (float)(off + d);      // flows: 0.0 + d == d (d is never -0.0)
+                if (q < 3 || blk != 5u) col[(row0 + (uint32_t)q) * 64u] = v;   // z[23] does not exist
+            }
+            if (blk == 0u) col[0] = 0.0f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double nn = -0.2 + (0.2 - -0.2) * u01(w[q]);           // :104 uniform: low + (high-low)*u
+                const double b = hi ? base_load(4 + q) : base_load(q);
+                col[(17u + 4u * (blk - 6u) + (uint32_t)q) * 64u] = (float)(b * (1.0 + nn));   // :105
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) n[16 + i] = (double)(2.0f * z[16 + i]);      // :144
     }
 
     // module-level check functions :10-30 (pre-state, clipped action)
@@ -247,7 +298,8 @@ struct PowerGrid {
     }
 
     // _dynamics :112-153
-    __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const double (&nz)[KS],
+    template <class NZ>
+    __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const NZ (&nz)[KS],
                                     float dt, double /*dt64*/, float (&o)[S])
     {
         float ngen[8], load[8];
@@ -262,16 +314,28 @@ struct PowerGrid {
         const float imb = sum8(ngen) - sum8(load);                       // :127-129
         const float fd = fdiv_c((-1.0f * s[0]) + imb, 5.0f);                  // :132
         o[0] = s[0] + fd * dt;                                           // :133
+        if constexpr (std::is_same<NZ, float>::value) {                  // float32-valued noise: see fast_noise_t
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            o[1 + i] = (float)((double)s[1 + i] + nz[i]);                // :136-137 fp64 add, one rounding
-            o[9 + i] = ngen[i];
-            double l = (double)s[17 + i] + nz[8 + i];                    // :140-141
-            l = (l < 0.0) ? 0.0 : l;
-            o[17 + i] = (float)l;
+            for (int i = 0; i < 8; ++i) {
+                o[1 + i] = s[1 + i] + nz[i];                             // :136-137
+                o[9 + i] = ngen[i];
+                const float l = s[17 + i] + nz[8 + i];                   // :140-141
+                o[17 + i] = (l < 0.0f) ? 0.0f : l;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) o[25 + i] = s[25 + i] + nz[16 + i];   // :144
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                o[1 + i] = (float)((double)s[1 + i] + nz[i]);            // :136-137 fp64 add, one rounding
+                o[9 + i] = ngen[i];
+                double l = (double)s[17 + i] + nz[8 + i];                // :140-141
+                l = (l < 0.0) ? 0.0 : l;
+                o[17 + i] = (float)l;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) o[25 + i] = (float)((double)s[25 + i] + nz[16 + i]);   // :144
         }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) o[25 + i] = (float)((double)s[25 + i] + nz[16 + i]);   // :144
     }
 
     // _compute_reward :155-177 (float32 terms, fp64 economic term, fp64 total)
@@ -307,6 +371,9 @@ struct PowerGrid {
 // RobotAssembly-v0  (environments/robot_assembly.py), S=24 A=7, fp64 internals
 // =================================================================================
 struct RobotAssembly {
+    static constexpr bool COOP_RESET = false;
+    static constexpr int RESET_ROWS = 1;
+    using fast_noise_t = double;
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
     static constexpr bool SHARED_STEP_BLOCK = false;
@@ -478,6 +545,9 @@ constexpr int NIG_SPEC_MAXSTEPS[4] = {NIG_SPEC_MAXSTEPS_LIST};
 
 template <int K>
 struct SpecPlant {
+    static constexpr bool COOP_RESET = false;
+    static constexpr int RESET_ROWS = 1;
+    using fast_noise_t = double;
     static constexpr int NP = NIG_SPEC_NP[K], A = NIG_SPEC_NA[K], S = NP + A + 3, ID = 5 + K;
     static constexpr int KS = 2, KR = NP, MAX_STEPS = NIG_SPEC_MAXSTEPS[K];
     static constexpr int ROW_E = NP + A, ROW_ECUM = NP + A + 1, ROW_T = NP + A + 2;
@@ -614,6 +684,9 @@ struct StepResult {
 // IndustrialEnv.__init__ (base.py:44) overwrites the 1.0 assigned at :65 before it.
 // =================================================================================
 struct AdvancedChemicalReactor {
+    static constexpr bool COOP_RESET = false;
+    static constexpr int RESET_ROWS = 1;
+    using fast_noise_t = double;
     static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
     static constexpr bool SHARED_STEP_BLOCK = false;
@@ -712,6 +785,9 @@ struct AdvancedChemicalReactor {
 // 532-537; self.episode_step :331,345 never set).  State layout as actually built at :217-224.
 // =================================================================================
 struct AdvancedPowerGrid {
+    static constexpr bool COOP_RESET = false;
+    static constexpr int RESET_ROWS = 1;
+    using fast_noise_t = double;
     static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
     static constexpr bool SHARED_STEP_BLOCK = false;

@@ -103,9 +103,9 @@ __device__ __forceinline__ void post_core(const float (&n)[Env::S], const float 
     out.terminated = term; out.truncated = trunc; out.shutdown = ncrit > 0;   // info['critical_shutdown'], base.py:210
 }
 
-template <class Env>
+template <class Env, class NZ>
 __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[Env::A],
-                                          const double (&nz)[Env::KS > 0 ? Env::KS : 1], int step_pre,
+                                          const NZ (&nz)[Env::KS > 0 ? Env::KS : 1], int step_pre,
                                           int max_steps, float dt32, double dt, uint32_t cmask,
                                           float (&n)[Env::S], StepResult<Env> &out)
 {
@@ -153,8 +153,8 @@ __device__ __forceinline__ u32x4 pair_block(const RngKey &k)
     if constexpr (Env::SHARED_STEP_BLOCK) return Env::step_block(k);
     else return u32x4{0u, 0u, 0u, 0u};
 }
-template <class Env>
-__device__ __forceinline__ void pair_noise(uint32_t w0, uint32_t w1, const float4 *tab, double (&n)[Env::KS > 0 ? Env::KS : 1])
+template <class Env, class NZ>
+__device__ __forceinline__ void pair_noise(uint32_t w0, uint32_t w1, const float4 *tab, NZ (&n)[Env::KS > 0 ? Env::KS : 1])
 {
     if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise(w0, w1, tab, n);
 }
@@ -163,13 +163,13 @@ __device__ __forceinline__ void pair_fetch(uint32_t w0, uint32_t w1, const float
 {
     if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise_fetch(w0, w1, tab, f);
 }
-template <class Env>
-__device__ __forceinline__ void pair_eval(const ProbitFetch (&f)[Env::KS > 0 ? Env::KS : 1], double (&n)[Env::KS > 0 ? Env::KS : 1])
+template <class Env, class NZ>
+__device__ __forceinline__ void pair_eval(const ProbitFetch (&f)[Env::KS > 0 ? Env::KS : 1], NZ (&n)[Env::KS > 0 ? Env::KS : 1])
 {
     if constexpr (Env::SHARED_STEP_BLOCK) Env::step_noise_eval(f, n);
 }
-template <class Env>
-__device__ __forceinline__ void draw_one(const RngKey &k, double (&n)[Env::KS > 0 ? Env::KS : 1])
+template <class Env, class NZ>
+__device__ __forceinline__ void draw_one(const RngKey &k, NZ (&n)[Env::KS > 0 ? Env::KS : 1])
 {
     if constexpr (Env::KS > 0) Env::draw_step(k, n);
 }
@@ -250,6 +250,33 @@ struct LaneTally {
     }
 };
 
+// Wave-cooperative reset (envs with COOP_RESET): the lanes of `m` (ballot of the finishing lanes of this wave)
+// get their initial states from work items (finishing lane, generator block) spread over all 64 lanes; an item
+// writes the state rows its block feeds into column `owner` of the wave-private LDS image img[RESET_ROWS][64], the owners
+// read their column back.  No block barrier.  DS operations of one wave execute in order, so the reads see the
+// writes issued before them without a wait in between; the fences only pin the compiler's ordering.
+// `lane_gi0` = global env index of the wave's lane 0, `t` = launch counter of the step that finished.
+template <class Env>
+__device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsigned lane, float *img, unsigned char *lst,
+                                           uint64_t lane_gi0, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
+                                           const float4 *tab, float (&n)[Env::S])
+{
+    constexpr int LOG2 = Env::RESET_ITEMS_LOG2;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (mine) lst[rank] = (unsigned char)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int total = __popcll(m) << LOG2;
+    for (int i = (int)lane; i < total; i += 64) {
+        const unsigned owner = lst[i >> LOG2];
+        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)i & ((1u << LOG2) - 1u), img + owner);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < Env::S; ++k) n[k] = img[k * 64 + lane];
+    }
+}
+
 // One launch = IndustrialEnv.step for every lane.
 //
 // Memory shape: every row pointer is block-uniform (SGPR base) and the lane adds a 32-bit offset,
@@ -268,8 +295,11 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     constexpr int NWAVE = BLOCK / 64;
-    __shared__ unsigned short s_list[BLOCK];
-    __shared__ int s_cnt[NWAVE];
+    constexpr bool COOP = Env::COOP_RESET && !PARITY;          // wave-cooperative auto-reset (fast mode): coop_reset above
+    __shared__ unsigned short s_list[COOP ? 1 : BLOCK];
+    __shared__ int s_cnt[COOP ? 1 : NWAVE];
+    __shared__ float s_img[COOP ? NWAVE * Env::RESET_ROWS * 64 : 1];
+    __shared__ unsigned char s_wlist[COOP ? BLOCK : 1];
 
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;                  // block-uniform
@@ -282,7 +312,8 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
     const float *act_row = p.actions + base;
     uint32_t ctr = NIG_CTR_DONE;
     float s[S], a[A], n[S];
-    double nz[KSN];
+    using nz_t = std::conditional_t<PARITY, double, typename Env::fast_noise_t>;   // injected draws are fp64
+    nz_t nz[KSN];
     if (in_range) {
         ctr = ctr_row[tid];
 #pragma unroll
@@ -321,7 +352,7 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
     if constexpr (KS > 0) {
         if constexpr (!PARITY) Env::draw_step(key, nz);
     } else {
-        nz[0] = 0.0;
+        nz[0] = (nz_t)0;
     }
 
     // ---- IndustrialEnv.step in registers --------------------------------------------------
@@ -355,10 +386,12 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
             if (autoreset) { nctr = 0u; fl |= NIG_FLAG_DID_RESET; }
             else nctr |= NIG_CTR_DONE;
         }
-        if (!need_reset) {                        // a resetting lane's state is written by the compacted pass below
-            float *so = p.state + base;
+        if constexpr (!COOP) {
+            if (!need_reset) {                    // a resetting lane's state is written by the compacted pass below
+                float *so = p.state + base;
 #pragma unroll
-            for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
+                for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
+            }
         }
         (p.ctr + base)[tid] = nctr;
         if (p.tally) (p.ep_ret + base)[tid] = ret;
@@ -371,6 +404,19 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
         if (p.reward64) (p.reward64 + base)[tid] = 0.0;
     }
 
+    if constexpr (COOP) {
+        // every wave renews its own finishing lanes (all 64 lanes work, whatever their own state), then stores
+        const unsigned long long m = __ballot(need_reset);
+        if (m != 0ull)
+            coop_reset<Env>(m, need_reset, tid & 63u, s_img + (tid >> 6) * (Env::RESET_ROWS * 64), s_wlist + (tid >> 6) * 64,
+                            p.env0 + (uint64_t)(base + (tid & ~63u)), t_now, p.seed_lo, p.seed_hi, s_probit, n);
+        if (active) {
+            float *so = p.state + base;
+#pragma unroll
+            for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
+        }
+        return;
+    }
     // ---- compacted auto-reset: IndustrialEnv.reset (base.py:133-155) for the finished lanes ----
     if (!autoreset) return;                       // block-uniform
     const unsigned wave = tid >> 6, lane = tid & 63u;
@@ -422,13 +468,18 @@ struct RolloutArgs {
     uint32_t out_stride;                         // elements between per-step reward/flag rows (0: overwrite)
     float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional trajectory, [n_steps][S][ld] ...
     int obs_aos;                                                     // ... or row-major transitions [n_steps][B][S]
+    uint32_t block0;            // first 256-lane block of this launch (the ragged last block is a launch of its own)
 };
 
 // OUT: 0 = no per-step outputs, 1 = reward + flag word, 2 = + observation rows [S][ld],
 //      3 = + observation row-major [B][S].  Compile-time so that the number of stores per
 // iteration is static and the wait for the prefetched action is a counted vmcnt(N), not a
 // full drain of the iteration's stores.
-template <class Env, int OUT, bool PAIRED>
+// FULL: every lane of every block of the launch exists (the host launches the batch's whole 256-lane blocks with
+// FULL = true and a ragged last block on its own with FULL = false).  Without lane predication the loop's loads
+// and stores sit in one basic block, so the waits for the prefetched actions stay counted vmcnt(N) instead of
+// the vmcnt(0) drains the waitcnt pass has to place behind exec-masked memory operations.
+template <class Env, int OUT, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
@@ -440,7 +491,16 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     // every wave for a few active lanes.  ChemicalReactor (0.3 % of lanes per step) keeps the
     // barrier-free divergent form.
     constexpr bool COMPACT = Env::COMPACT_RESET;
+    // COOP (PowerGrid: ~11 lanes of every wave finish in every step): each WAVE produces the initial states of
+    // its own finishing lanes cooperatively -- work item = (finishing lane, generator block) -> a few state rows,
+    // spread over all 64 lanes through a wave-private LDS image.  No block barrier (waves keep drifting), the
+    // generator runs at ~70 % lane utilisation instead of one wave carrying the whole block's resets while three
+    // wait (53 % of the wave cycles of round 1's kernel were spent at those barriers).
+    constexpr bool COOP = Env::COOP_RESET;
+    static_assert(!(COMPACT && COOP), "one reset scheme per env");
     constexpr int NWAVE = BLOCK / 64;
+    __shared__ float s_img[COOP ? NWAVE * Env::RESET_ROWS * 64 : 1];   // per wave: [RESET_ROWS][64] initial-state rows of one phase, column = owner lane
+    __shared__ unsigned char s_wlist[COOP ? BLOCK : 1];                // per wave: lanes that finished, in lane order
     __shared__ float s_init[COMPACT ? S * BLOCK : 1];
     __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
     __shared__ int s_cnt[COMPACT ? NWAVE : 1];
@@ -448,9 +508,12 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
-    const uint32_t base = blockIdx.x * BLOCK;
-    const bool in_range = base + tid < p.B;
-    if constexpr (!COMPACT) {
+    const uint32_t base = (blockIdx.x + q.block0) * BLOCK;
+    const bool in_range = FULL ? true : (base + tid < p.B);
+    if constexpr (FULL) {
+    } else if constexpr (COOP) {
+        if (base + (tid & ~63u) >= p.B) return;   // whole wave out of range; a partial wave keeps all 64 lanes as workers
+    } else if constexpr (!COMPACT) {
         if (!in_range) return;       // compacting blocks keep every thread for the barriers.  (From here on the
     }                                // compiler knows in_range: no exec masking around the loop's loads and stores.)
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;      // step k uses t_base + k + 1
@@ -490,8 +553,9 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     // Four steps for the envs whose step is short enough that four copies stay inside the I-cache.
     constexpr int DEPTH = PAIRED ? 4 : 2;
     float buf[DEPTH][A];
-    double nzA[KSN], nzB[KSN];
-    nzA[0] = 0.0; nzB[0] = 0.0;
+    using nz_t = typename Env::fast_noise_t;
+    nz_t nzA[KSN], nzB[KSN];
+    nzA[0] = (nz_t)0; nzB[0] = (nz_t)0;
     uint32_t kept0 = 0u, kept1 = 0u;          // words 2-3 of the current pair's block
     int slot = 0;
     // Wave-uniform running pointers instead of it * stride products: the per-step 64-bit scalar
@@ -504,9 +568,9 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
     // block-uniform: lanes can be frozen (finished and waiting for reset -- also on an auto-reset handle whose lanes
     // were never reset, left out by reset(mask) or marked done by set_state: base.py:159-160 -- or out of range)
-    const bool may_freeze = !autoreset || (p.hflags & HF_MAY_HOLD_DONE) != 0 || base + BLOCK > p.B;
+    const bool may_freeze = !autoreset || (p.hflags & HF_MAY_HOLD_DONE) != 0 || (!FULL && base + BLOCK > p.B);
 
-    auto one_step = [&](auto pos_tag, float (&abuf)[A], double (&nz)[KSN], const int it) __attribute__((always_inline)) {
+    auto one_step = [&](auto pos_tag, float (&abuf)[A], nz_t (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const bool frozen = may_freeze && (ctr & NIG_CTR_DONE) != 0;   // no auto-reset: base.py:159-160
@@ -584,7 +648,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             v4f v[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) v[k] = tr[(16 * S % 64 == 0 || lane + 64u * k < 16u * S) ? lane + 64u * k : 0u];
-            if (wave_env0 + 64u <= p.B) {          // wave-uniform: the whole wave exists
+            if (FULL || wave_env0 + 64u <= p.B) {  // wave-uniform: the whole wave exists
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
                     if (16 * S % 64 == 0 || lane + 64u * k < 16u * S) stream_store(oo + lane + 64u * k, v[k]);
@@ -623,7 +687,16 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             if (tally) { lt.episode((double)ret, step, viol_ep, res.ncrit); ret = (ret_t)0; }
             if (!autoreset) ctr |= NIG_CTR_DONE;
         }
-        if constexpr (!COMPACT) {
+        if constexpr (COOP) {
+            const unsigned long long m = __ballot(done && autoreset);
+            if (m != 0ull) {                       // wave-uniform
+                const unsigned lane = tid & 63u, wave = tid >> 6;
+                coop_reset<Env>(m, done, lane, s_img + wave * (Env::RESET_ROWS * 64), s_wlist + wave * 64,
+                                p.env0 + (uint64_t)(base + (tid & ~63u)), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi,
+                                s_probit, n);
+                if (done) ctr = 0u;
+            }
+        } else if constexpr (!COMPACT) {
             if (done && autoreset) {               // divergent per-lane reset (base.py:133-155)
                 double rn[KR > 0 ? KR : 1];
                 Env::draw_init(key, rn);
@@ -826,7 +899,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
 
     uint32_t ctr = (p.ctr + base)[tid];
     float s[S], a[A], n[S], integ[A], eprev[A];
-    double nz[KSN];
+    typename Env::fast_noise_t nz[KSN];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[tid];
     // PID memory lives in the handle (baseline_agents.py:55-80: integral and previous error are the agent's,
@@ -888,7 +961,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
 #pragma unroll
             for (int j = 0; j < A; ++j) stream_store(ao + j * q.ld_act_out + tid, a[j]);
         }
-        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
@@ -985,7 +1058,7 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
 
     uint32_t ctr = in_range ? p.ctr[li] : (uint32_t)NIG_CTR_DONE;
     float s[S], a[A], n[S];
-    double nz[KSN];
+    typename Env::fast_noise_t nz[KSN];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + k * p.ld_state)[li] : 0.0f;
     double ret = (tally && in_range) ? p.ep_ret[li] : 0.0;
@@ -1084,7 +1157,7 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
             }
         }
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
-        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0.0;
+        if constexpr (KS > 0) Env::draw_step(key, nz); else nz[0] = 0;
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
@@ -1222,15 +1295,25 @@ static void launch_step(const StepArgs &a, bool parity, unsigned grid, hipStream
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-template <class Env, bool PAIRED>
-static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
+template <class Env, bool PAIRED, bool FULL>
+static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
     switch (out_mode) {
-    case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    case 2: hipLaunchKernelGGL((rollout_kernel<Env, 2, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
-    default: hipLaunchKernelGGL((rollout_kernel<Env, 3, PAIRED>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    case 2: hipLaunchKernelGGL((rollout_kernel<Env, 2, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
+    default: hipLaunchKernelGGL((rollout_kernel<Env, 3, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
     }
+}
+
+// the batch's whole 256-lane blocks in one launch without lane predication, a ragged last block in its own
+template <class Env, bool PAIRED>
+static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*grid*/, hipStream_t st)
+{
+    const unsigned n_full = q.s.B / BLOCK;
+    RolloutArgs r = q;
+    if (n_full > 0) { r.block0 = 0; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full, st); }
+    if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
 }
 
 // t0 = launch counter of the call's first step (host-known: rollouts are never graph-captured)

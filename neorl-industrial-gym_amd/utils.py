@@ -140,9 +140,10 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
         mask[:k] = 1
         env.ctr.fill_(_lib.CTR_DONE)
         env.reset(mask=mask)
-        # one step more than the cap: the Advanced envs truncate on the step AFTER the cap
-        # (advanced_chemical_reactor.py:351 tests episode_step before its increment); finished lanes are frozen
-        (env.rollout_mlp if fused_mlp else env.rollout_policy)(env.max_episode_steps + 1)
+        # the Advanced envs truncate on the step AFTER the cap (advanced_chemical_reactor.py:351 and
+        # advanced_power_grid.py:331 test episode_step before its increment): one step more for them
+        extra = 1 if env.env_id.startswith("Advanced") else 0
+        (env.rollout_mlp if fused_mlp else env.rollout_policy)(env.max_episode_steps + extra)
         remaining -= k
     while remaining > 0:
         k = min(B, remaining)
