@@ -340,6 +340,51 @@ int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, vo
 int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out,
                   double *reward64_out, uint32_t *flags_out, void *stream);
 
+/*
+ * Mixed batch: several environment types in ONE padded structure-of-arrays batch (BASELINE config
+ * "all 7 envs mixed-batch, heterogeneous state dims, padded SoA").  Lanes are grouped in contiguous
+ * segments, one env type each, every segment starting on a multiple of 256 lanes (wavefronts and
+ * blocks are homogeneous); all segments share ONE observation matrix float [S_max][ld] (rows >= S of
+ * a segment stay zero), and actions / per-step outputs use the same column layout ([A_max][ld],
+ * [n_steps][ld]).  The reference has no vectorised env at all: this stands in for N_total calls of
+ * utils.make with different ids stepped by one loop (performance_benchmark.py:106-133 over a list of envs).
+ * Global lane index of column c = env_index0 + c (keys the generator: results do not depend on the
+ * other segments).  The fused rollout over the whole mixed batch is ONE kernel launch: a block finds
+ * its segment in a table passed with the launch, the most expensive envs' blocks are issued first.
+ */
+#define NIG_MIXED_MAX_SEGMENTS 12
+typedef struct nig_mixed nig_mixed;
+typedef struct nig_mixed_info {
+    int32_t n_segments, state_dim_max, action_dim_max, reserved;
+    int64_t lanes;                                   /* sum of the segment counts                       */
+    int64_t ld;                                      /* columns of the padded matrices (256-aligned)    */
+    int32_t env[NIG_MIXED_MAX_SEGMENTS];             /* env id of segment k                             */
+    int64_t offset[NIG_MIXED_MAX_SEGMENTS];          /* first column of segment k                       */
+    int64_t count[NIG_MIXED_MAX_SEGMENTS];           /* lanes of segment k                              */
+} nig_mixed_info;
+
+/* flags as for nig_create (apply to every segment); seed / env_index0 as for nig_create */
+int nig_create_mixed(int32_t n_segments, const int32_t *env_ids, const int64_t *counts, int device, uint64_t seed,
+                     uint64_t env_index0, uint32_t flags, nig_mixed **out);
+int nig_mixed_destroy(nig_mixed *m);
+int nig_mixed_get_info(const nig_mixed *m, nig_mixed_info *out);
+float *nig_mixed_state(const nig_mixed *m);                 /* device float [S_max][ld], library-owned          */
+nig_handle *nig_mixed_segment(const nig_mixed *m, int32_t k);   /* borrowed handle of segment k: tallies, counters,
+                                                               constraint mask, nig_step ... all per-handle calls */
+int nig_mixed_reset(nig_mixed *m, void *stream);            /* IndustrialEnv.reset for every lane, fast mode    */
+int nig_mixed_fill_actions(nig_mixed *m, uint32_t t, float *actions /* [A_max][ld] */, void *stream);
+/* n_steps of IndustrialEnv.step for every lane of every segment in ONE launch; arguments as nig_rollout with
+ * ld_act = ld: action_ring slot s at action_ring + s*slot_stride laid out [A_max][ld]; reward_out / flags_out
+ * rows [ld] (both or neither), row of step k at base + k*out_stride (0 = overwrite). */
+int nig_mixed_rollout(nig_mixed *m, int32_t n_steps, const float *action_ring, int64_t slot_stride, int32_t ring_len,
+                      float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream);
+/* The same single launch for handles the caller created itself (e.g. bound to its own matrix with
+ * nig_bind_state): handle k uses columns [lane_offsets[k], lane_offsets[k] + batch_k) of the action ring and of
+ * the output rows (pitch ld_act / out_stride as above).  All handles on one device, fast mode. */
+int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, int32_t n_handles, int32_t n_steps,
+                      const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
+                      float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream);
+
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream);

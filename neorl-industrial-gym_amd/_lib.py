@@ -30,6 +30,8 @@ SYMBOLS = [
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
     "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
     "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
+    "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
+    "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed",
 ]
 
 
@@ -55,6 +57,17 @@ class Policy(C.Structure):
 
 
 POLICY_AFFINE, POLICY_PID = 1, 2
+
+
+MIXED_MAX_SEGMENTS = 12
+
+
+class MixedInfo(C.Structure):
+    """nig_mixed_info (include/nig.h)."""
+    _fields_ = [("n_segments", C.c_int32), ("state_dim_max", C.c_int32), ("action_dim_max", C.c_int32),
+                ("reserved", C.c_int32), ("lanes", C.c_int64), ("ld", C.c_int64),
+                ("env", C.c_int32 * MIXED_MAX_SEGMENTS), ("offset", C.c_int64 * MIXED_MAX_SEGMENTS),
+                ("count", C.c_int64 * MIXED_MAX_SEGMENTS)]
 
 
 class NigError(RuntimeError):
@@ -111,6 +124,17 @@ def lib():
     L.nig_reset_host.argtypes = [vp, vp, vp, vp]
     L.nig_step_host.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.nig_rollout.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
+    L.nig_create_mixed.argtypes = [i32, C.POINTER(i32), C.POINTER(i64), C.c_int, u64, u64, u32, C.POINTER(vp)]
+    L.nig_mixed_destroy.argtypes = [vp]
+    L.nig_mixed_get_info.argtypes = [vp, C.POINTER(MixedInfo)]
+    L.nig_mixed_state.restype = vp
+    L.nig_mixed_state.argtypes = [vp]
+    L.nig_mixed_segment.restype = vp
+    L.nig_mixed_segment.argtypes = [vp, i32]
+    L.nig_mixed_reset.argtypes = [vp, vp]
+    L.nig_mixed_fill_actions.argtypes = [vp, u32, vp, vp]
+    L.nig_mixed_rollout.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64, vp]
+    L.nig_rollout_mixed.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, i32, vp, i64, i64, i32, vp, vp, i64, vp]
     _lib = L
     return L
 

@@ -529,7 +529,7 @@ class MixedBatchedEnv:
     launches one kernel per segment, each on its own HIP stream."""
 
     def __init__(self, segments, device="cuda:0", seed: int = 0x5EED, autoreset: bool = True, tally: bool = False,
-                 env_index0: int = 0, fused: bool = False):
+                 env_index0: int = 0, fused: bool = True):
         self.device = torch.device(device)
         segs = list(segments.items()) if isinstance(segments, dict) else list(segments)
         self.S_max = max(int(_lib.env_spec(ENV_IDS[e]).state_dim) for e, _ in segs)
@@ -551,6 +551,10 @@ class MixedBatchedEnv:
                                                   autoreset=autoreset, tally=tally,
                                                   bind_state=self.state_soa[:, o:o + int(n)]))
         self._streams = [torch.cuda.Stream(device=self.device) for _ in self.envs]
+        self.fused = bool(fused)
+        n = len(self.envs)
+        self._hs = (C.c_void_p * n)(*[e._h for e in self.envs])
+        self._offs = (C.c_int64 * n)(*offs)
 
     def _fan(self, fn):
         cur = torch.cuda.current_stream(self.device)
@@ -581,6 +585,22 @@ class MixedBatchedEnv:
     def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out=None, flags_out=None):
         """action_ring: float32 [R, A_max, LD]; optional reward/flags outputs [n_steps, LD]."""
         assert action_ring.shape[1:] == (self.A_max, self.ld)
+        if self.fused:
+            assert action_ring.dtype == torch.float32 and action_ring.stride(2) == 1 and action_ring.stride(1) == self.ld
+            assert (reward_out is None) == (flags_out is None)
+            os_ = 0
+            if reward_out is not None:
+                assert reward_out.dtype == torch.float32 and flags_out.dtype == torch.int32
+                assert reward_out.shape[-1] == self.ld and flags_out.shape[-1] == self.ld
+                os_ = reward_out.stride(0) if reward_out.dim() == 2 else 0
+                assert (flags_out.stride(0) if flags_out.dim() == 2 else 0) == os_
+            L = self.envs[0]._L
+            with torch.cuda.device(self.envs[0]._dev_index):
+                _lib.check(L.nig_rollout_mixed(self._hs, self._offs, len(self.envs), int(n_steps),
+                                               C.c_void_p(action_ring.data_ptr()), self.ld, action_ring.stride(0),
+                                               action_ring.shape[0], _ptr(reward_out), _ptr(flags_out), os_,
+                                               self.envs[0]._stream()))
+            return
 
         def f(env, o):
             env.rollout(n_steps, action_ring[:, :env.action_dim, o:o + env.batch],

@@ -749,6 +749,171 @@ int nig_plan_destroy(nig_plan *p)
     return NIG_OK;
 }
 
+// ---- mixed batch -------------------------------------------------------------------------------
+struct nig_mixed {
+    int n;
+    int device;
+    nig_handle *seg[NIG_MIXED_MAX_SEGMENTS];
+    int64_t off[NIG_MIXED_MAX_SEGMENTS];
+    int64_t ld, lanes;
+    int s_max, a_max;
+    float *state;              // [s_max][ld], owned
+};
+
+// relative cost of one env-step (fused rollout, measured per-env rates): launch order = most expensive first
+static int env_cost(int env)
+{
+    static const int C[NIG_NUM_ENVS] = {10, 44, 50, 15, 20, 14, 9, 17, 29};
+    return C[env];
+}
+
+int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, int32_t n_handles, int32_t n_steps,
+                      const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
+                      float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream)
+{
+    if (!handles || !lane_offsets || n_handles <= 0 || n_handles > NIG_MIXED_MAX_SEGMENTS)
+        return fail(NIG_ERR_INVALID, "nig_rollout_mixed: 1..12 handles%s");
+    if (!action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: bad argument%s");
+    if ((reward_out == nullptr) != (flags_out == nullptr))
+        return fail(NIG_ERR_INVALID, "nig_rollout_mixed: reward_out and flags_out go together (both or neither)%s");
+    if (ld_act <= 0 || ld_act > NIG_MAX_PITCH || slot_stride > 0xffffffffLL)
+        return fail(NIG_ERR_INVALID, "nig_rollout_mixed: ld_act outside [1, 2^26] or slot_stride >= 2^32%s");
+    if (out_stride != 0 && out_stride > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: out_stride > 2^26%s");
+    if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: n_steps*out_stride >= 2^32%s");
+    int order[NIG_MIXED_MAX_SEGMENTS];
+    int a_max = 0;
+    for (int k = 0; k < n_handles; ++k) {
+        const nig_handle *h = handles[k];
+        if (!h) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: NULL handle%s");
+        if (h->device != handles[0]->device) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: handles on different devices%s");
+        if (lane_offsets[k] < 0 || lane_offsets[k] + h->B > ld_act || (out_stride != 0 && lane_offsets[k] + h->B > out_stride))
+            return fail(NIG_ERR_INVALID, "nig_rollout_mixed: a segment does not fit the row pitch%s");
+        if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: launch counter would wrap%s");
+        if (SPECS[h->env].action_dim > a_max) a_max = SPECS[h->env].action_dim;
+        order[k] = k;
+    }
+    if (slot_stride < (int64_t)a_max * ld_act) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: slot_stride smaller than one [A_max][ld_act] slot%s");
+    for (int i = 1; i < n_handles; ++i)           // insertion sort: most expensive env first, ties in segment order
+        for (int j = i; j > 0 && env_cost(handles[order[j]]->env) > env_cost(handles[order[j - 1]]->env); --j) {
+            const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
+        }
+    MixedArgs m;
+    memset(&m, 0, sizeof m);
+    m.n_seg = n_handles;
+    uint32_t blocks = 0;
+    for (int i = 0; i < n_handles; ++i) {
+        nig_handle *h = handles[order[i]];
+        const int64_t o = lane_offsets[order[i]];
+        RolloutArgs &q = m.seg[i];
+        q.s = base_step_args(h);
+        q.s.actions = action_ring + o; q.s.ld_act = (uint32_t)ld_act;
+        q.s.reward = reward_out ? reward_out + o : nullptr;
+        q.s.flags = flags_out ? flags_out + o : nullptr;
+        q.s.t_ptr = nullptr; q.s.t_off = h->t;
+        q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride;
+        q.out_stride = (uint32_t)out_stride; q.block0 = 0;
+        blocks += grid_for(h->B);
+        m.blk_end[i] = blocks;
+        m.env[i] = h->env;
+    }
+    HIP_TRY(hipSetDevice(handles[0]->device));
+    nig_launch_mixed_rollout(reward_out ? 1 : 0, m, blocks, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    for (int k = 0; k < n_handles; ++k) handles[k]->t += (uint32_t)n_steps;
+    return NIG_OK;
+}
+
+int nig_create_mixed(int32_t n_segments, const int32_t *env_ids, const int64_t *counts, int device, uint64_t seed,
+                     uint64_t env_index0, uint32_t flags, nig_mixed **out)
+{
+    if (!out) return fail(NIG_ERR_INVALID, "nig_create_mixed: out is NULL%s");
+    *out = nullptr;
+    if (!env_ids || !counts || n_segments <= 0 || n_segments > NIG_MIXED_MAX_SEGMENTS)
+        return fail(NIG_ERR_INVALID, "nig_create_mixed: 1..12 segments%s");
+    nig_mixed *m = new (std::nothrow) nig_mixed();
+    if (!m) return fail(NIG_ERR_INVALID, "nig_create_mixed: out of host memory%s");
+    memset(m, 0, sizeof *m);
+    m->n = n_segments; m->device = device;
+    int64_t off = 0;
+    for (int k = 0; k < n_segments; ++k) {
+        if (env_ids[k] < 0 || env_ids[k] >= NIG_NUM_ENVS || counts[k] <= 0 || counts[k] > NIG_MAX_BATCH) {
+            delete m;
+            return fail(NIG_ERR_INVALID, "nig_create_mixed: bad env id or lane count%s");
+        }
+        m->off[k] = off;
+        off += align_up(counts[k], BLOCK);            // every segment starts on a block boundary
+        m->lanes += counts[k];
+        if (SPECS[env_ids[k]].state_dim > m->s_max) m->s_max = SPECS[env_ids[k]].state_dim;
+        if (SPECS[env_ids[k]].action_dim > m->a_max) m->a_max = SPECS[env_ids[k]].action_dim;
+    }
+    m->ld = off;
+    if (m->ld > NIG_MAX_PITCH) { delete m; return fail(NIG_ERR_INVALID, "nig_create_mixed: more than 2^26 columns%s"); }
+    int rc = NIG_OK;
+    for (int k = 0; k < n_segments && rc == NIG_OK; ++k)
+        rc = nig_create(env_ids[k], counts[k], device, seed, env_index0 + (uint64_t)m->off[k], 0, 0.0, flags, nullptr, &m->seg[k]);
+    if (rc == NIG_OK) {
+        const size_t bytes = (size_t)m->s_max * m->ld * sizeof(float);
+        hipError_t e = hipMalloc((void **)&m->state, bytes);
+        if (e == hipSuccess) e = hipMemset(m->state, 0, bytes);      // rows >= S of a segment stay zero
+        if (e != hipSuccess) rc = fail(NIG_ERR_HIP, "nig_create_mixed: state matrix: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < n_segments && rc == NIG_OK; ++k) rc = nig_bind_state(m->seg[k], m->state + m->off[k], m->ld);
+    if (rc != NIG_OK) { nig_mixed_destroy(m); return rc; }
+    *out = m;
+    return NIG_OK;
+}
+
+int nig_mixed_destroy(nig_mixed *m)
+{
+    if (!m) return NIG_OK;
+    for (int k = 0; k < m->n; ++k) nig_destroy(m->seg[k]);
+    if (m->state) (void)hipFree(m->state);
+    delete m;
+    return NIG_OK;
+}
+
+int nig_mixed_get_info(const nig_mixed *m, nig_mixed_info *out)
+{
+    if (!m || !out) return fail(NIG_ERR_INVALID, "nig_mixed_get_info: NULL argument%s");
+    memset(out, 0, sizeof *out);
+    out->n_segments = m->n; out->state_dim_max = m->s_max; out->action_dim_max = m->a_max;
+    out->lanes = m->lanes; out->ld = m->ld;
+    for (int k = 0; k < m->n; ++k) { out->env[k] = m->seg[k]->env; out->offset[k] = m->off[k]; out->count[k] = m->seg[k]->B; }
+    return NIG_OK;
+}
+
+float *nig_mixed_state(const nig_mixed *m) { return m ? m->state : nullptr; }
+
+nig_handle *nig_mixed_segment(const nig_mixed *m, int32_t k) { return (m && k >= 0 && k < m->n) ? m->seg[k] : nullptr; }
+
+int nig_mixed_reset(nig_mixed *m, void *stream)
+{
+    if (!m) return fail(NIG_ERR_INVALID, "nig_mixed_reset: NULL handle%s");
+    for (int k = 0; k < m->n; ++k) {
+        const int rc = nig_reset(m->seg[k], nullptr, nullptr, 0, stream);
+        if (rc != NIG_OK) return rc;
+    }
+    return NIG_OK;
+}
+
+int nig_mixed_fill_actions(nig_mixed *m, uint32_t t, float *actions, void *stream)
+{
+    if (!m || !actions) return fail(NIG_ERR_INVALID, "nig_mixed_fill_actions: NULL argument%s");
+    for (int k = 0; k < m->n; ++k) {
+        const int rc = nig_fill_actions(m->seg[k], t, actions + m->off[k], m->ld, stream);
+        if (rc != NIG_OK) return rc;
+    }
+    return NIG_OK;
+}
+
+int nig_mixed_rollout(nig_mixed *m, int32_t n_steps, const float *action_ring, int64_t slot_stride, int32_t ring_len,
+                      float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream)
+{
+    if (!m) return fail(NIG_ERR_INVALID, "nig_mixed_rollout: NULL handle%s");
+    return nig_rollout_mixed(m->seg, m->off, m->n, n_steps, action_ring, m->ld, slot_stride, ring_len, reward_out, flags_out,
+                             out_stride, stream);
+}
+
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream)
 {
     if (!h || !actions || ld_act < h->B) return fail(NIG_ERR_INVALID, "nig_fill_actions: bad argument%s");

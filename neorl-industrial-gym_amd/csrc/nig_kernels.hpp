@@ -479,8 +479,24 @@ struct RolloutArgs {
 // FULL = true and a ragged last block on its own with FULL = false).  Without lane predication the loop's loads
 // and stores sit in one basic block, so the waits for the prefetched actions stay counted vmcnt(N) instead of
 // the vmcnt(0) drains the waitcnt pass has to place behind exec-masked memory operations.
+// LDS of one rollout block, carved from ONE buffer the kernel declares (the per-env kernels size it for their own
+// env and output mode, the mixed-batch kernel for the largest of its envs): generator table, then the env's
+// reset scratch, then the per-wave transpose image of the row-major trajectory.
+template <class Env, int OUT>
+struct RolloutLds {
+    static constexpr int NWAVE = BLOCK / 64;
+    static constexpr int OFF_PROBIT = 0;
+    static constexpr int OFF_IMG = OFF_PROBIT + 768 * 16;                                          // float [NWAVE][RESET_ROWS][64]
+    static constexpr int OFF_WLIST = OFF_IMG + (Env::COOP_RESET ? NWAVE * Env::RESET_ROWS * 64 * 4 : 0);   // uchar [BLOCK]
+    static constexpr int OFF_INIT = OFF_WLIST + (Env::COOP_RESET ? BLOCK : 0);                      // float [S][BLOCK]
+    static constexpr int OFF_LIST = OFF_INIT + (Env::COMPACT_RESET ? Env::S * BLOCK * 4 : 0);       // ushort [BLOCK]
+    static constexpr int OFF_CNT = OFF_LIST + (Env::COMPACT_RESET ? BLOCK * 2 : 0);                 // int [NWAVE]
+    static constexpr int OFF_TR = OFF_CNT + (Env::COMPACT_RESET ? 16 : 0);                          // v4f [NWAVE][16 S]
+    static constexpr int BYTES = OFF_TR + (OUT == 3 ? NWAVE * 16 * Env::S * 16 : 0);
+};
+
 template <class Env, int OUT, bool PAIRED, bool FULL>
-__global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(const RolloutArgs q)
+__device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
@@ -499,16 +515,18 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     constexpr bool COOP = Env::COOP_RESET;
     static_assert(!(COMPACT && COOP), "one reset scheme per env");
     constexpr int NWAVE = BLOCK / 64;
-    __shared__ float s_img[COOP ? NWAVE * Env::RESET_ROWS * 64 : 1];   // per wave: [RESET_ROWS][64] initial-state rows of one phase, column = owner lane
-    __shared__ unsigned char s_wlist[COOP ? BLOCK : 1];                // per wave: lanes that finished, in lane order
-    __shared__ float s_init[COMPACT ? S * BLOCK : 1];
-    __shared__ unsigned short s_list[COMPACT ? BLOCK : 1];
-    __shared__ int s_cnt[COMPACT ? NWAVE : 1];
-    __shared__ v4f s_tr[OUT == 3 ? NWAVE : 1][OUT == 3 ? 16 * S : 1];          // per-wave transpose of the row-major observation rows (64 x S floats)
-    NIG_STAGE_PROBIT(s_probit);
+    using Lds = RolloutLds<Env, OUT>;
+    float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
+    float *const s_img = reinterpret_cast<float *>(smem + Lds::OFF_IMG);         // per wave: [RESET_ROWS][64] initial states, column = owner lane
+    unsigned char *const s_wlist = smem + Lds::OFF_WLIST;                        // per wave: lanes that finished, in lane order
+    float *const s_init = reinterpret_cast<float *>(smem + Lds::OFF_INIT);
+    unsigned short *const s_list = reinterpret_cast<unsigned short *>(smem + Lds::OFF_LIST);
+    int *const s_cnt = reinterpret_cast<int *>(smem + Lds::OFF_CNT);
+    v4f *const s_tr = reinterpret_cast<v4f *>(smem + Lds::OFF_TR);               // per wave: [16 S] transpose image of the row-major observation rows (64 x S floats)
+    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit[i_] = NIG_PROBIT[i_];
+    __syncthreads();                       // every thread of the block passes here before any early exit
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
-    const uint32_t base = (blockIdx.x + q.block0) * BLOCK;
     const bool in_range = FULL ? true : (base + tid < p.B);
     if constexpr (FULL) {
     } else if constexpr (COOP) {
@@ -614,11 +632,11 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         }
         if constexpr (OUT == 3) {                  // stage this lane's row; read back transposed below
             if constexpr (S % 4 == 0) {
-                v4f *tr = s_tr[tid >> 6] + (tid & 63u) * (S / 4);
+                v4f *tr = s_tr + (tid >> 6) * (16 * S) + (tid & 63u) * (S / 4);
 #pragma unroll
                 for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
             } else {
-                float *tr = reinterpret_cast<float *>(s_tr[tid >> 6]) + (tid & 63u) * S;
+                float *tr = reinterpret_cast<float *>(s_tr + (tid >> 6) * (16 * S)) + (tid & 63u) * S;
 #pragma unroll
                 for (int k = 0; k < S; ++k) tr[k] = n[k];
             }
@@ -642,7 +660,7 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
             // contiguous KiB each.  (DS operations of one wave execute in order: the reads see the writes
             // issued above without a wait in between.)
             const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
-            const v4f *tr = s_tr[tid >> 6];
+            const v4f *tr = s_tr + (tid >> 6) * (16 * S);
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
             constexpr int NV = (16 * S + 63) / 64;  // float4 pieces per lane: the wave's block is 64*S floats = 16*S float4
             v4f v[NV];
@@ -786,6 +804,23 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
         if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
     }
 }
+
+template <class Env, int OUT, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(const RolloutArgs q)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RolloutLds<Env, OUT>::BYTES];
+    rollout_body<Env, OUT, PAIRED, FULL>(q, (blockIdx.x + q.block0) * BLOCK, smem);
+}
+
+// Mixed-batch launch (nig_mixed.hip): per-segment rollout arguments + the block -> segment table, in launch order.
+constexpr int MIXED_MAX_SEG = NIG_MIXED_MAX_SEGMENTS;
+struct MixedArgs {
+    RolloutArgs seg[MIXED_MAX_SEG];
+    uint32_t blk_end[MIXED_MAX_SEG];     // cumulative block count up to and including segment k
+    int env[MIXED_MAX_SEG];
+    int n_seg;
+};
+static_assert(sizeof(MixedArgs) <= 4000, "kernel argument segment is 4 KiB");
 
 // ------------------------------------------------------------------------------------------
 // Closed-loop fused rollout: action = on-device policy(observation) -> IndustrialEnv.step, n steps
@@ -1357,6 +1392,9 @@ static const EnvLaunch *env_launch_table()
 }
 
 }  // namespace nig
+
+// nig_mixed.hip
+void nig_launch_mixed_rollout(int out_mode, const nig::MixedArgs &m, unsigned grid, hipStream_t st);
 
 #define NIG_DEFINE_ENV_LAUNCH(EnvType, fn_name) \
     const nig::EnvLaunch *fn_name() { return nig::env_launch_table<nig::EnvType>(); }

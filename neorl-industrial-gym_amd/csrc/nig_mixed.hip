@@ -1,0 +1,63 @@
+// nig_mixed.hip -- BASELINE config "all envs mixed-batch": ONE fused-rollout launch over a padded SoA batch
+// whose contiguous 256-aligned lane segments run different environment types.
+//
+// A block looks its segment up in a small table passed with the kernel arguments (blocks are numbered in
+// LAUNCH order: the segments with the most expensive env step first, so the cheap envs fill the tail of the
+// launch), then runs that env's rollout body -- the same device function the per-env kernels wrap, hence the
+// same results bit for bit.  One launch instead of one per segment: no per-kernel tails (a 150 k-lane PowerGrid
+// segment alone fills the chip 1.14 times: its second round ran at 14 % occupancy), no launch fan-out.
+// The price of one kernel for all envs: every block runs under the register allocation of the hungriest body.
+#include "nig_kernels.hpp"
+
+namespace nig {
+
+template <int OUT>
+struct MixedLds {
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int BYTES =
+        cmax(cmax(cmax(RolloutLds<ChemicalReactor, OUT>::BYTES, RolloutLds<PowerGrid, OUT>::BYTES),
+                  cmax(RolloutLds<RobotAssembly, OUT>::BYTES, RolloutLds<AdvancedChemicalReactor, OUT>::BYTES)),
+             cmax(cmax(RolloutLds<AdvancedPowerGrid, OUT>::BYTES, RolloutLds<HVACControl, OUT>::BYTES),
+                  cmax(cmax(RolloutLds<WaterTreatment, OUT>::BYTES, RolloutLds<SteelAnnealing, OUT>::BYTES),
+                       RolloutLds<SupplyChain, OUT>::BYTES)));
+};
+
+// OUT: 0 = no per-step outputs, 1 = reward + flag word rows (the padded [n_steps][ld] matrices).
+template <int OUT>
+__global__ void __launch_bounds__(BLOCK, 2) mixed_rollout_kernel(const MixedArgs m)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MixedLds<OUT>::BYTES];
+    // Segment of this block (block-uniform).  The table is walked with COMPILE-TIME indices and scalar selects: a
+    // run-time index into the by-value argument struct makes hipcc copy all of it to scratch and turns every
+    // global access of the bodies into a flat one (pointer provenance lost).  ~60 dwords x 11 selects per block,
+    // once, against a quarter of a million instructions of rollout.
+    RolloutArgs q = m.seg[0];
+    int env = m.env[0];
+    uint32_t blk0 = 0u;
+#pragma unroll
+    for (int j = 1; j < MIXED_MAX_SEG; ++j) {
+        if (j < m.n_seg && blockIdx.x >= m.blk_end[j - 1]) { q = m.seg[j]; env = m.env[j]; blk0 = m.blk_end[j - 1]; }
+    }
+    const uint32_t base = (blockIdx.x - blk0) * BLOCK;         // first lane of the block inside its segment
+    // unpaired form for ChemicalReactor (its launch-counter parity is per handle), predicated lanes (ragged segments)
+    switch (env) {
+    case NIG_ENV_CHEMICAL_REACTOR: rollout_body<ChemicalReactor, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_POWER_GRID: rollout_body<PowerGrid, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_ROBOT_ASSEMBLY: rollout_body<RobotAssembly, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_ADV_CHEMICAL_REACTOR: rollout_body<AdvancedChemicalReactor, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_ADV_POWER_GRID: rollout_body<AdvancedPowerGrid, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_HVAC_CONTROL: rollout_body<HVACControl, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_WATER_TREATMENT: rollout_body<WaterTreatment, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_STEEL_ANNEALING: rollout_body<SteelAnnealing, OUT, false, false>(q, base, smem); break;
+    default: rollout_body<SupplyChain, OUT, false, false>(q, base, smem); break;
+    }
+}
+
+}  // namespace nig
+
+void nig_launch_mixed_rollout(int out_mode, const nig::MixedArgs &m, unsigned grid, hipStream_t st)
+{
+    using namespace nig;
+    if (out_mode == 0) hipLaunchKernelGGL((mixed_rollout_kernel<0>), dim3(grid), dim3(BLOCK), 0, st, m);
+    else hipLaunchKernelGGL((mixed_rollout_kernel<1>), dim3(grid), dim3(BLOCK), 0, st, m);
+}
