@@ -56,6 +56,20 @@ def main():
     path = os.path.join(out, f"traffic_{tag}.json")
     json.dump(summary, open(path, "w"), indent=1)
     print(json.dumps(summary, indent=1))
+    # merge into profiles/traffic.json under the key bench.py looks up: <env>_<B>_<mode>_<outputs|step>
+    outputs = args[args.index("--outputs") + 1] if "--outputs" in args else "full"
+    want = "rollout_kernel" if mode == "rollout" else "step_kernel"
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
+    try:
+        allt = json.load(open(tpath))
+    except Exception:
+        allt = {}
+    for k, v in summary.items():
+        if want in k:
+            rec = {kk: vv for kk, vv in v.items() if kk != "detail"}
+            rec["source"] = f"profiles/r02/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on copy_rows_kernel)"
+            allt[f"{env}_{B}_{mode}_{outputs if mode == 'rollout' else 'step'}"] = rec
+    json.dump(allt, open(tpath, "w"), indent=1)
 
 
 if __name__ == "__main__":
