@@ -211,6 +211,23 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act,
              float *final_obs, int64_t ld_obs, void *stream);
 
 /*
+ * IndustrialEnv.step with FLOAT64 actions: double [A][ld_act], everything else as nig_step.
+ * The reference's own callers hand np.float64 arrays to step() -- get_dataset (chemical_reactor.py:364-393,
+ * power_grid.py:216-233, robot_assembly.py:266-290) and the baseline agents (benchmarks/baseline_agents.py:28-114)
+ * -- and base.py:167 clips without casting, so under NumPy >= 2 every expression that touches an action element is
+ * float64 and float64 spreads through what depends on it until a value is stored into the float32 state vector
+ * (ChemicalReactor: temperature, pressure, flows, concentration, level and the reward; PowerGrid: generation,
+ * frequency deviation, the action penalty; RobotAssembly: the joint update, the action penalty).  This entry point
+ * follows that arithmetic for the three NumPy envs (pinned by the reference's outputs, tests/golden/<env>_g5.npz and
+ * _g6.npz: state words bit-exact); the other envs convert the action to float32 on entry, as their own code would.
+ * reward_out is the float64 reward rounded to float32; ChemicalReactor's reward is float64 here (np.float32 - np.float64).
+ */
+int nig_step64(nig_handle *h, const double *actions, int64_t ld_act,
+               const double *step_noise, const double *reset_noise, int64_t ld_noise,
+               float *reward_out, double *reward64_out, uint32_t *flags_out,
+               float *final_obs, int64_t ld_obs, void *stream);
+
+/*
  * A plan = n_steps consecutive nig_step launches in fast mode recorded once as a hipGraph
  * and replayed with one call (the per-step launch is otherwise host-bound at small batch).
  * Step k (0-based) of every replay reads its actions from ring slot k % ring_len:
@@ -339,6 +356,9 @@ int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t 
 int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, void *stream);
 int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out,
                   double *reward64_out, uint32_t *flags_out, void *stream);
+/* the same with float64 actions double [A][B] (nig_step64's arithmetic) */
+int nig_step_host64(nig_handle *h, const double *actions, const double *step_noise, float *state_out,
+                    double *reward64_out, uint32_t *flags_out, void *stream);
 
 /*
  * Mixed batch: several environment types in ONE padded structure-of-arrays batch (BASELINE config

@@ -242,14 +242,18 @@ class BatchedIndustrialEnv:
              layout: Optional[str] = None):
         """IndustrialEnv.step (base.py:157-213) for every lane: one kernel launch.
 
-        actions: [A, B] (SoA, zero-copy) or [B, A] float32 tensor/array on any device;
+        actions: [A, B] (SoA, zero-copy) or [B, A] tensor/array on any device; float32, or float64 --
+        upstream clips without casting (base.py:167), so a float64 action vector makes NumPy evaluate
+        the action-dependent arithmetic in float64: float64 input goes through nig_step64, which
+        follows that (CR / PG / RA; the other envs take float32).  Other dtypes are cast to float32.
         `layout` ("soa"/"aos") disambiguates when A == B (default then: [B, A]).
         Returns (obs [B,S] view, reward f32 [B], terminated [B], truncated [B], StepInfo).
         """
         A, B = self.action_dim, self.batch
         a = torch.as_tensor(actions, device=self.device)
-        if a.dtype != torch.float32:
-            a = a.to(torch.float32)      # the reference semantics pinned here are float32 actions
+        act64 = a.dtype == torch.float64
+        if not act64 and a.dtype != torch.float32:
+            a = a.to(torch.float32)
         if layout in ("soa", "aos"):
             soa = layout == "soa"
         else:
@@ -262,6 +266,11 @@ class BatchedIndustrialEnv:
             act, ld_act = a, a.stride(0)                      # native SoA, zero-copy
         elif (not soa) and a.stride(0) == 1 and a.stride(1) >= B:
             act, ld_act = a, a.stride(1)                      # [B,A] view of an SoA buffer, zero-copy
+        elif act64:
+            if getattr(self, "_act64_soa", None) is None:
+                self._act64_soa = torch.zeros(self.action_dim, self.ld, dtype=torch.float64, device=self.device)
+            self._act64_soa[:, :B].copy_(a if soa else a.t())
+            act, ld_act = self._act64_soa, self.ld
         else:
             self._act_soa[:, :B].copy_(a if soa else a.t())   # one transposing copy
             act, ld_act = self._act_soa, self.ld
@@ -272,9 +281,9 @@ class BatchedIndustrialEnv:
             assert final_obs.dtype == torch.float32 and final_obs.shape[0] == self.state_dim and final_obs.stride(1) == 1
             ld_obs = final_obs.stride(0)
         with torch.cuda.device(self._dev_index):
-            _lib.check(self._L.nig_step(self._h, _ptr(act), ld_act, _ptr(sn), _ptr(rn), B,
-                                        _ptr(self.reward), _ptr(self.reward64), _ptr(self.flags),
-                                        _ptr(final_obs), ld_obs, self._stream()))
+            _lib.check((self._L.nig_step64 if act64 else self._L.nig_step)(
+                self._h, _ptr(act), ld_act, _ptr(sn), _ptr(rn), B, _ptr(self.reward), _ptr(self.reward64),
+                _ptr(self.flags), _ptr(final_obs), ld_obs, self._stream()))
         info = StepInfo(self.flags, int(self.spec.n_constraints))
         return self.obs, self.reward, info.terminated, info.truncated, info
 

@@ -77,6 +77,15 @@ __global__ void reduce_tally_stage2(const double *scratch, int nblk, double *out
     out[r] = acc;
 }
 
+// float64 action rows -> float32 (envs whose own arithmetic converts the action on entry)
+__global__ void __launch_bounds__(BLOCK) narrow_rows_kernel(const double *src, int64_t ld_src, float *dst, int64_t ld_dst,
+                                                            int rows, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= B) return;
+    for (int k = 0; k < rows; ++k) dst[(int64_t)k * ld_dst + i] = (float)src[(int64_t)k * ld_src + i];
+}
+
 __global__ void __launch_bounds__(BLOCK) copy_rows_kernel(const float *src, int64_t ld_src, float *dst, int64_t ld_dst,
                                                           int rows, int64_t B)
 {
@@ -113,6 +122,7 @@ struct nig_handle {
     nig_policy pol_host;   // staging copy (must outlive the async H2D copy)
     bool has_policy;
     float *mlp_stream;     // device copy of the MFMA operand stream of the MLP actor (owned)
+    float *act32;          // nig_step64 on an env that takes float32 actions: the narrowed rows [A][ld] (owned, lazy)
     float *pid_mem;        // PID policies: per-lane integral / previous error, float [2*A][ld] (owned, lazy)
     bool may_hold_done;    // some lane may carry NIG_CTR_DONE although the handle auto-resets (see HF_MAY_HOLD_DONE)
     char *hst_pinned;      // host-buffer entry points: pinned staging + its device mirror (owned, lazy)
@@ -301,7 +311,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
     h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false; h->mlp_stream = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0;
+    h->has_policy = false; h->mlp_stream = nullptr; h->act32 = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -325,6 +335,7 @@ int nig_destroy(nig_handle *h)
     if (!h) return NIG_OK;
     if (h->mlp_stream) (void)hipFree(h->mlp_stream);
     if (h->pid_mem) (void)hipFree(h->pid_mem);
+    if (h->act32) (void)hipFree(h->act32);
     if (h->hst_dev) (void)hipFree(h->hst_dev);
     if (h->hst_pinned) (void)hipHostFree(h->hst_pinned);
     if (h->owns_ws && h->ws) (void)hipFree(h->ws);
@@ -413,6 +424,42 @@ int nig_step(nig_handle *h, const float *actions, int64_t ld_act, const double *
     a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = (uint32_t)ld_obs;
     a.t_ptr = nullptr; a.t_off = h->t;
     dispatch_step(h, a, parity, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return NIG_OK;
+}
+
+int nig_step64(nig_handle *h, const double *actions, int64_t ld_act, const double *step_noise, const double *reset_noise,
+               int64_t ld_noise, float *reward_out, double *reward64_out, uint32_t *flags_out, float *final_obs,
+               int64_t ld_obs, void *stream)
+{
+    if (!h) return fail(NIG_ERR_INVALID, "nig_step64: NULL handle%s");
+    if (!actions || ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step64: actions NULL or ld_act outside [batch, 2^26]%s");
+    const EnvLaunch *L = launch_of(h->env);
+    if (!L->step64) {                             // this env's own arithmetic takes the action as float32
+        const int A = SPECS[h->env].action_dim;
+        if (!h->act32) HIP_TRY(hipMalloc((void **)&h->act32, (size_t)A * h->lay.ld * sizeof(float)));
+        hipLaunchKernelGGL(narrow_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, (hipStream_t)stream, actions, ld_act,
+                           h->act32, h->lay.ld, A, h->B);
+        HIP_TRY(hipGetLastError());
+        return nig_step(h, h->act32, h->lay.ld, step_noise, reset_noise, ld_noise, reward_out, reward64_out, flags_out,
+                        final_obs, ld_obs, stream);
+    }
+    const nig_env_spec &sp = SPECS[h->env];
+    const bool autoreset = (h->flags & NIG_F_AUTORESET) != 0;
+    const bool parity = (step_noise != nullptr) || (reset_noise != nullptr);
+    if (parity) {
+        if (sp.k_step > 0 && !step_noise) return fail(NIG_ERR_INVALID, "nig_step64: parity mode needs step_noise%s");
+        if (autoreset && !reset_noise) return fail(NIG_ERR_INVALID, "nig_step64: parity mode with auto-reset needs reset_noise%s");
+        if (ld_noise < h->B || ld_noise > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_step64: ld_noise outside [batch, 2^26]%s");
+    }
+    if (final_obs && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH)) return fail(NIG_ERR_INVALID, "nig_step64: ld_obs outside [batch, 2^26]%s");
+    h->t += 1;
+    StepArgs a = base_step_args(h);
+    a.actions64 = actions; a.ld_act = (uint32_t)ld_act;
+    a.step_noise = step_noise; a.reset_noise = reset_noise; a.ld_noise = (uint32_t)ld_noise;
+    a.reward = reward_out; a.reward64 = reward64_out; a.flags = flags_out; a.final_obs = final_obs; a.ld_obs = (uint32_t)ld_obs;
+    a.t_ptr = nullptr; a.t_off = h->t;
+    L->step64(a, parity, grid_for(h->B), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NIG_OK;
 }
@@ -601,7 +648,7 @@ static HostStage host_stage_layout(const nig_handle *h)
     const size_t K = (size_t)(sp.k_step > sp.k_reset ? sp.k_step : sp.k_reset);
     HostStage L;
     L.off_act = 0;
-    L.off_noise = (size_t)align_up((int64_t)(sp.action_dim * B * 4), 256);
+    L.off_noise = (size_t)align_up((int64_t)(sp.action_dim * B * 8), 256);     // float32 or float64 action rows
     L.off_state = L.off_noise + (size_t)align_up((int64_t)(K * B * 8), 256);
     L.off_rew = L.off_state + (size_t)align_up((int64_t)(sp.state_dim * B * 4), 256);
     L.off_flags = L.off_rew + (size_t)align_up((int64_t)(B * 8), 256);
@@ -649,8 +696,23 @@ int nig_reset_host(nig_handle *h, const double *init_noise, float *state_out, vo
     return NIG_OK;
 }
 
+static int step_host_impl(nig_handle *h, const void *actions, bool act64, const double *step_noise, float *state_out,
+                          double *reward64_out, uint32_t *flags_out, void *stream);
+
 int nig_step_host(nig_handle *h, const float *actions, const double *step_noise, float *state_out, double *reward64_out,
                   uint32_t *flags_out, void *stream)
+{
+    return step_host_impl(h, actions, false, step_noise, state_out, reward64_out, flags_out, stream);
+}
+
+int nig_step_host64(nig_handle *h, const double *actions, const double *step_noise, float *state_out, double *reward64_out,
+                    uint32_t *flags_out, void *stream)
+{
+    return step_host_impl(h, actions, true, step_noise, state_out, reward64_out, flags_out, stream);
+}
+
+static int step_host_impl(nig_handle *h, const void *actions, bool act64, const double *step_noise, float *state_out,
+                          double *reward64_out, uint32_t *flags_out, void *stream)
 {
     if (!h || !actions || !state_out || !reward64_out || !flags_out) return fail(NIG_ERR_INVALID, "nig_step_host: NULL argument%s");
     const nig_env_spec &sp = SPECS[h->env];
@@ -659,8 +721,9 @@ int nig_step_host(nig_handle *h, const float *actions, const double *step_noise,
     if (rc != NIG_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t B = (size_t)h->B;
-    memcpy(h->hst_pinned + L.off_act, actions, (size_t)sp.action_dim * B * 4);
-    size_t up = (size_t)sp.action_dim * B * 4;
+    const size_t act_bytes = (size_t)sp.action_dim * B * (act64 ? 8 : 4);
+    memcpy(h->hst_pinned + L.off_act, actions, act_bytes);
+    size_t up = act_bytes;
     const double *dn = nullptr;
     if (step_noise && sp.k_step > 0) {
         memcpy(h->hst_pinned + L.off_noise, step_noise, (size_t)sp.k_step * B * 8);
@@ -675,8 +738,10 @@ int nig_step_host(nig_handle *h, const float *actions, const double *step_noise,
     char *io = zero_copy ? h->hst_pinned : h->hst_dev;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
     if (dn) dn = (const double *)(io + L.off_noise);
-    rc = nig_step(h, (const float *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
-                  (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream);
+    rc = act64 ? nig_step64(h, (const double *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
+                            (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream)
+               : nig_step(h, (const float *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
+                          (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream);
     if (rc != NIG_OK) return rc;
     // state rows gathered next to reward64 and flags: one download for everything the call returns
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,

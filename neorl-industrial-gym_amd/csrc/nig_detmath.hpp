@@ -59,6 +59,33 @@ __device__ __forceinline__ float det_expf(float x)
     return res;
 }
 
+// e^x in double: Cody-Waite by ln2 (hi/lo), fdlibm's degree-5 kernel on r^2, exact two-step scaling; < 1 ulp.
+// Stands in for np.exp on a float64 scalar (chemical_reactor.py:177 when the action is float64).  The oracle runs
+// the same operation sequence.
+__device__ __forceinline__ double det_exp(double x)
+{
+    const double k = floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double hi = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    const double lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    double c = 4.13813679705723846039e-08;
+    c = __builtin_fma(c, t, -1.65339022054652515390e-06);
+    c = __builtin_fma(c, t, 6.61375632143793436117e-05);
+    c = __builtin_fma(c, t, -2.77777777770155933842e-03);
+    c = __builtin_fma(c, t, 1.66666666666666019037e-01);
+    c = r - t * c;
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const double kc = fmin(fmax(k, -2000.0), 2000.0);      // only reached by inputs that are overridden below
+    const int ki = (int)kc;
+    const int k1 = ki / 2, k2 = ki - k1;
+    double res = (y * __longlong_as_double((long long)(k1 + 1023) << 52)) * __longlong_as_double((long long)(k2 + 1023) << 52);
+    res = (x > 709.78) ? __builtin_inf() : res;
+    res = (x < -745.13) ? 0.0 : res;
+    res = (x != x) ? x : res;
+    return res;
+}
+
 // ln(x) for a positive normal float (used by det_powf).
 __device__ __forceinline__ float det_logf(float x)
 {

@@ -16,6 +16,10 @@
 
 namespace nig {
 
+// Result of one IndustrialEnv.step for one lane (defined below); R = the type the reward has at that point of the
+// reference's arithmetic: Env::reward_t with float32 actions, double with float64 actions.
+template <class Env, class R = typename Env::reward_t> struct StepResult;
+
 // Python builtin max(a, b) / min(a, b): second argument only if strictly greater / less.
 template <class T> __device__ __forceinline__ T pymax(T a, T b) { return (b > a) ? b : a; }
 template <class T> __device__ __forceinline__ T pymin(T a, T b) { return (b < a) ? b : a; }
@@ -144,6 +148,57 @@ struct ChemicalReactor {
         const float nlevel = pymax(0.0f, pymin(100.0f, level + ((nfeed - 20.0f) * 0.1f) * 0.1f)); // :204-205
         o[0] = nT; o[1] = nP; o[2] = ncool; o[3] = nfeed; o[4] = nconc; o[5] = ncat; o[6] = nhx;
         o[7] = nrel; o[8] = nestop; o[9] = nalarm; o[10] = nlevel; o[11] = bt + 0.1f;       // :208
+    }
+
+    // ---- float64 actions (what the reference's own callers pass: get_dataset :364-393, baseline agents; base.py:167
+    // clips without casting): every expression touching an action element is float64 under NumPy >= 2 and float64
+    // spreads until a value is stored into the float32 state (:209-224).  Pinned by tests/golden/cr_g5.npz, cr_g6.npz.
+    static constexpr bool HAS_ACT64 = true;
+    __device__ static uint32_t violated(const float (&s)[S], const double (&)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f};
+        return violated(s, none);
+    }
+    __device__ static void dynamics(const float (&s)[S], const double (&a)[A], const double (&nz)[KS],
+                                    float dt32, double dt, float (&o)[S])
+    {
+        const float T = s[0], P = s[1], cool = s[2], feed = s[3], conc = s[4], cat = s[5];
+        const float hx = s[6], relief = s[7], estop = s[8], alarm = s[9], level = s[10], bt = s[11];
+        if (!(estop < 0.5f)) {                                           // emergency branch :131-134: the action is not read
+            const float none[A] = {0.0f, 0.0f, 0.0f};
+            dynamics(s, none, nz, dt32, dt, o);
+            return;
+        }
+        const double hp = a[0] * 50000.0, cadj = a[1] * 0.1, fadj = a[2] * 0.1;     // :127-129 float64
+        const float kc = (0.1f * conc) * fdiv_c(cat, 100.0f);                       // :137-139 float32
+        const float rh = kc * 10000.0f;
+        const float ch = ((cool * 100.0f) * (T - hx)) * 0.1f;                       // :141 float32
+        double dT = ((hp + (double)rh) - (double)ch) / 418000.0;                    // :143-146
+        dT = dT + nz[0];                                                            // :149
+        const double nT = (double)T + dT * 0.1;                                     // :151
+        double nP = (double)P * (nT / (double)T) + (double)(((conc * 0.1f) * 1000.0f) * 0.1f);   // :155-158
+        nP = nP + nz[1];                                                            // :159
+        const double nrel = pymax(0.0, pymin(100.0, (double)relief + (nP - 506625.0) * 0.001));  // :162-163
+        if (nrel > 0.0) nP = pymax(101325.0, nP - (nrel * 0.01) * 10000.0);         // :166-168
+        const double ncool = pymax(10.0, pymin(100.0, (double)cool + cadj));        // :171
+        const double nfeed = pymax(5.0, pymin(50.0, (double)feed + fadj));          // :172
+        const double rr = (double)kc * det_exp((-(nT - 320.0)) / 20.0);             // :175-178 np.exp on a float64 scalar
+        const double nconc = pymax(0.0, (double)conc + (rr - nfeed * 0.001) * 0.1); // :180-182
+        const float ncat = pymax(50.0f, cat - ((nT > 340.0) ? 0.001f : 0.0001f));   // :185-186 float32
+        const float nhx = hx + (0.1f * ((290.0f + cool * 0.1f) - hx)) * 0.1f;       // :189-190 float32
+        const bool warn = (nT > 345.0) || (nP > 480000.0);                          // :196
+        const bool trip = (nT > 350.0) || (nP > 506625.0);                          // :199
+        const double nlevel = pymax(0.0, pymin(100.0, (double)level + ((nfeed - 20.0) * 0.1) * 0.1));   // :204-205
+        o[0] = (float)nT; o[1] = (float)nP; o[2] = (float)ncool; o[3] = (float)nfeed; o[4] = (float)nconc;
+        o[5] = ncat; o[6] = nhx; o[7] = (float)nrel; o[8] = trip ? 1.0f : estop; o[9] = (warn || trip) ? 1.0f : alarm;
+        o[10] = (float)nlevel; o[11] = bt + 0.1f;                                   // :208-224 np.array(..., dtype=float32)
+    }
+    __device__ static double reward(const float (&n)[S], const double (&a)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f};
+        const float r = reward(n, none);                                 // float32 up to the action penalty (- 0 * 0.1 changes nothing)
+        const double ap = ((0.0 + fabs(a[0])) + fabs(a[1])) + fabs(a[2]);   // :268 float64
+        return (double)r - ap * 0.1;                                     // :269
     }
 
     // _compute_reward :228-270 on the NEXT state
@@ -338,6 +393,51 @@ struct PowerGrid {
         }
     }
 
+    // ---- float64 actions (power_grid.py:216-233 hands them over; pinned by tests/golden/pg_g5.npz, pg_g6.npz)
+    static constexpr bool HAS_ACT64 = true;
+    __device__ static uint32_t violated(const float (&s)[S], const double (&a)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t v = violated(s, none) & 3u;
+        bool g_ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double ng = (double)s[9 + i] + a[i];                   // float64 add, :29
+            g_ok = g_ok && (ng >= 0.0) && (ng <= 100.0);
+        }
+        return v | (g_ok ? 0u : 4u);
+    }
+    template <class NZ>
+    __device__ static void dynamics(const float (&s)[S], const double (&a)[A], const NZ (&nz)[KS],
+                                    float dt32, double dt, float (&o)[S])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        dynamics(s, none, nz, dt32, dt, o);                              // voltages, loads, line flows never see the action
+        double ngen[8];
+        float load[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double g = (double)s[9 + i] + a[i];                          // :124 np.clip(gen + a, 0, 100) in float64
+            g = (g < 0.0) ? 0.0 : g;
+            g = (g > 100.0) ? 100.0 : g;
+            ngen[i] = g;
+            load[i] = s[17 + i];
+        }
+        const double imb = sum8(ngen) - (double)sum8(load);              // :127-129
+        const double fd = ((double)(-1.0f * s[0]) + imb) / 5.0;          // :132 (-D * f is float32, the sum float64)
+        o[0] = (float)((double)s[0] + fd * dt);                          // :133
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[9 + i] = (float)ngen[i];
+    }
+    __device__ static double reward(const float (&n)[S], const double (&a)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        double a2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a2[i] = a[i] * a[i];
+        return reward(n, none) + (-5.0 * sum8(a2));                      // :173-175 (the float32 form adds -5.0f * 0 = -0.0)
+    }
+
     // _compute_reward :155-177 (float32 terms, fp64 economic term, fp64 total)
     __device__ static double reward(const float (&n)[S], const float (&a)[A])
     {
@@ -447,8 +547,37 @@ struct RobotAssembly {
     {
         double q[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            double d = (double)(s[7 + i] + a[i] * dt32);                 // :148 float32, then fp64 clip :149-153
+        for (int i = 0; i < 7; ++i) q[i] = (double)(s[7 + i] + a[i] * dt32);     // :148 float32
+        dynamics_from_joints(s, q, dt, o);
+    }
+    // float64 actions (robot_assembly.py:266-290 hands them over; pinned by ra_g5.npz, ra_g6.npz): :148 is float64
+    static constexpr bool HAS_ACT64 = true;
+    __device__ static uint32_t violated(const float (&s)[S], const double (&)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        return violated(s, none);
+    }
+    __device__ static void dynamics(const float (&s)[S], const double (&a)[A], const double (&)[1],
+                                    float /*dt32*/, double dt, float (&o)[S])
+    {
+        double q[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[i] = (double)s[7 + i] + a[i] * dt;
+        dynamics_from_joints(s, q, dt, o);
+    }
+    __device__ static double reward(const float (&n)[S], const double (&a)[A])
+    {
+        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        double ap = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ap = ap + a[i] * a[i];               // :211 float64, sequential
+        return reward_with_penalty(n, -0.1 * ap);
+    }
+    __device__ static void dynamics_from_joints(const float (&s)[S], double (&q)[7], double dt, float (&o)[S])
+    {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {                                    // fp64 clip :149-153
+            double d = q[i];
             d = (d < -PI) ? -PI : d;
             d = (d > PI) ? PI : d;
             q[i] = d;
@@ -479,18 +608,23 @@ struct RobotAssembly {
     // _compute_reward :190-222
     __device__ static double reward(const float (&n)[S], const float (&a)[A])
     {
+        float ap = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ap = ap + a[i] * a[i];               // :211
+        return reward_with_penalty(n, (double)(-0.1f * ap));
+    }
+    __device__ static double reward_with_penalty(const float (&n)[S], const double action_penalty)
+    {
         const float cr = 100.0f * n[23];                                 // :197
         const double dx = (double)n[0] - 0.3, dy = (double)n[1] - 0.0, dz = (double)n[2] - 0.4;
         const double dr = -10.0 * sqrt(dx * dx + dy * dy + dz * dz);     // :200-201
         const float fm = sqrtf((n[18] * n[18] + n[19] * n[19]) + n[20] * n[20]);   // :204 float32 norm
-        float ap = 0.0f, vp = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) ap = ap + a[i] * a[i];               // :211
+        float vp = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) vp = vp + n[14 + i] * n[14 + i];     // :214-215
         double tot = (double)cr + dr;                                    // :217-220, left to right
         tot = tot + ((fm > 30.0f) ? (double)(-50.0f * (fm - 30.0f)) : 0.0);   // :205-208
-        tot = tot + (double)(-0.1f * ap);
+        tot = tot + action_penalty;
         tot = tot + (double)(-0.5f * vp);
         return tot;
     }
@@ -546,6 +680,7 @@ constexpr int NIG_SPEC_MAXSTEPS[4] = {NIG_SPEC_MAXSTEPS_LIST};
 template <int K>
 struct SpecPlant {
     static constexpr bool COOP_RESET = false;
+    static constexpr bool HAS_ACT64 = false;     // build-specified plants are float32 by design
     static constexpr int RESET_ROWS = 1;
     using fast_noise_t = double;
     static constexpr int NP = NIG_SPEC_NP[K], A = NIG_SPEC_NA[K], S = NP + A + 3, ID = 5 + K;
@@ -661,9 +796,9 @@ using SteelAnnealing = SpecPlant<2>;
 using SupplyChain = SpecPlant<3>;
 
 // Result of one IndustrialEnv.step for one lane (filled by step_core or by an env's own step).
-template <class Env>
+template <class Env, class R>
 struct StepResult {
-    typename Env::reward_t reward;
+    R reward;
     uint32_t viol_bits;        // bit k: constraint k violated (up to 4)
     int nviol, ncrit;
     bool terminated, truncated, shutdown;
@@ -685,6 +820,7 @@ struct StepResult {
 // =================================================================================
 struct AdvancedChemicalReactor {
     static constexpr bool COOP_RESET = false;
+    static constexpr bool HAS_ACT64 = false;     // JAX with x64 off: a float64 action becomes float32 on entry
     static constexpr int RESET_ROWS = 1;
     using fast_noise_t = double;
     static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
@@ -710,7 +846,7 @@ struct AdvancedChemicalReactor {
 
     // step :195-366, _compute_reward :368-404, _check_termination :406-420, get_safety_metrics :422-450
     __device__ static void custom_step(const float (&s)[S], const float (&a)[A], int step_pre, int max_steps,
-                                       float dt, float (&o)[S], StepResult<AdvancedChemicalReactor> &out)
+                                       float dt, float (&o)[S], StepResult<AdvancedChemicalReactor, float> &out)
     {
         const float T = s[0], Tj = s[1], cA = s[3], cB = s[4], cC = s[5], cD = s[6];
         const float Ff = s[7], Fp = s[8], Fc = s[9], hc = s[10], mix = s[11];
@@ -786,6 +922,7 @@ struct AdvancedChemicalReactor {
 // =================================================================================
 struct AdvancedPowerGrid {
     static constexpr bool COOP_RESET = false;
+    static constexpr bool HAS_ACT64 = false;     // JAX with x64 off: a float64 action becomes float32 on entry
     static constexpr int RESET_ROWS = 1;
     using fast_noise_t = double;
     static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
@@ -823,7 +960,7 @@ struct AdvancedPowerGrid {
     // step :228-354, _solve_power_flow :356-407, _calculate_stability_margin :409-434,
     // _compute_reward :436-482, _check_termination :484-501, get_safety_metrics :503-537
     __device__ static void custom_step(const float (&s)[S], const float (&a)[A], int step_pre, int max_steps,
-                                       float dt, float (&o)[S], StepResult<AdvancedPowerGrid> &out)
+                                       float dt, float (&o)[S], StepResult<AdvancedPowerGrid, float> &out)
     {
         const bool emerg = a[7] > 0.5f;                                  // :246
         float sp[4], nf[4], nPg[4], nL[4];

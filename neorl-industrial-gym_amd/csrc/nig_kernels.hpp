@@ -57,6 +57,7 @@ struct StepArgs {
     uint32_t ld_state;                // pitch of the state rows (== ld unless the caller bound its own array)
     // caller-owned
     const float *actions; uint32_t ld_act;
+    const double *actions64;          // nig_step64: the same rows as float64 (actions is then unused)
     const double *step_noise; const double *reset_noise; uint32_t ld_noise;
     float *reward; double *reward64; uint32_t *flags; float *final_obs; uint32_t ld_obs;
     // scalars
@@ -73,23 +74,28 @@ constexpr uint32_t HF_MAY_HOLD_DONE = 0x10000u;
 // IndustrialEnv.step for one lane, entirely in registers (base.py:157-213): action clip, constraint
 // check on the pre-state and dynamics, then post_core = reward / penalties / termination on the
 // finished transition.
-template <class Env>
-__device__ __forceinline__ void clip_action(float (&a)[Env::A])
+// AT = float, or double when the caller hands float64 actions over (nig_step64): base.py:167 clips a float64 array
+// against the float32 bounds without casting, and the envs' arithmetic follows NumPy's promotion from there.
+template <class Env, class AT>
+__device__ __forceinline__ void clip_action(AT (&a)[Env::A])
 {
 #pragma unroll
     for (int k = 0; k < Env::A; ++k) {            // base.py:167 np.clip(action, -1, 1) == min(max(x,lo),hi)
-        float x = a[k];
-        x = (x < -1.0f) ? -1.0f : x;
-        x = (x > 1.0f) ? 1.0f : x;
+        AT x = a[k];
+        x = (x < (AT)-1) ? (AT)-1 : x;
+        x = (x > (AT)1) ? (AT)1 : x;
         a[k] = x;
     }
 }
 
-template <class Env>
-__device__ __forceinline__ void post_core(const float (&n)[Env::S], const float (&a)[Env::A], uint32_t vb,
-                                          int step_pre, int max_steps, StepResult<Env> &out)
+// the reward's type at the end of the reference's arithmetic: float64 as soon as the action is float64
+template <class Env, class AT> using reward_of = std::conditional_t<std::is_same<AT, double>::value, double, typename Env::reward_t>;
+
+template <class Env, class AT>
+__device__ __forceinline__ void post_core(const float (&n)[Env::S], const AT (&a)[Env::A], uint32_t vb,
+                                          int step_pre, int max_steps, StepResult<Env, reward_of<Env, AT>> &out)
 {
-    using R = typename Env::reward_t;
+    using R = reward_of<Env, AT>;
     R r = Env::reward(n, a);                      // base.py:176
 #pragma unroll
     for (int k = 0; k < 3; ++k)                   // base.py:179-183, constraint order
@@ -103,11 +109,11 @@ __device__ __forceinline__ void post_core(const float (&n)[Env::S], const float 
     out.terminated = term; out.truncated = trunc; out.shutdown = ncrit > 0;   // info['critical_shutdown'], base.py:210
 }
 
-template <class Env, class NZ>
-__device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[Env::A],
+template <class Env, class NZ, class AT>
+__device__ __forceinline__ void step_core(const float (&s)[Env::S], AT (&a)[Env::A],
                                           const NZ (&nz)[Env::KS > 0 ? Env::KS : 1], int step_pre,
                                           int max_steps, float dt32, double dt, uint32_t cmask,
-                                          float (&n)[Env::S], StepResult<Env> &out)
+                                          float (&n)[Env::S], StepResult<Env, reward_of<Env, AT>> &out)
 {
     if constexpr (Env::CUSTOM_STEP) {             // the Advanced envs override step() wholesale
         Env::custom_step(s, a, step_pre, max_steps, dt32, n, out);
@@ -115,16 +121,16 @@ __device__ __forceinline__ void step_core(const float (&s)[Env::S], float (&a)[E
         out.nviol = __popc(out.viol_bits);
         return;
     } else {
-        clip_action<Env>(a);
+        clip_action<Env, AT>(a);
         const uint32_t vb = Env::violated(s, a) & cmask;   // base.py:170 (and again :180, same inputs); cmask: base.py:224-228
         Env::dynamics(s, a, nz, dt32, dt, n);         // base.py:173
-        post_core<Env>(n, a, vb, step_pre, max_steps, out);
+        post_core<Env, AT>(n, a, vb, step_pre, max_steps, out);
     }
 }
 
 // The per-lane flag word of one step (include/nig.h NIG_FLAG_*).
-template <class Env>
-__device__ __forceinline__ uint32_t pack_flags(const StepResult<Env> &res, int step)
+template <class Env, class R>
+__device__ __forceinline__ uint32_t pack_flags(const StepResult<Env, R> &res, int step)
 {
     uint32_t f = (res.terminated ? NIG_FLAG_TERMINATED : 0u) | (res.truncated ? NIG_FLAG_TRUNCATED : 0u) |
                  ((res.viol_bits & 7u) << NIG_FLAG_VIOL_SHIFT) | (((uint32_t)res.nviol & 3u) << NIG_FLAG_NVIOL_SHIFT) |
@@ -289,13 +295,15 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
 // initial states are produced by the first ceil(n/64) waves at full lane utilisation (with 18 % of
 // PowerGrid lanes finishing per step every wave would otherwise run the whole reset path for a
 // handful of active lanes).
-template <class Env, bool PARITY>
-__global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const StepArgs p)
+// ACT64: the action rows are float64 (nig_step64; CR / PG / RA only: the envs whose NumPy arithmetic then changes).
+template <class Env, bool PARITY, bool ACT64 = false>
+__global__ void __launch_bounds__(BLOCK, ACT64 ? 2 : Env::STEP_WAVES) step_kernel(const StepArgs p)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     constexpr int NWAVE = BLOCK / 64;
     constexpr bool COOP = Env::COOP_RESET && !PARITY;          // wave-cooperative auto-reset (fast mode): coop_reset above
+    using act_t = std::conditional_t<ACT64, double, float>;
     __shared__ unsigned short s_list[COOP ? 1 : BLOCK];
     __shared__ int s_cnt[COOP ? 1 : NWAVE];
     __shared__ float s_img[COOP ? NWAVE * Env::RESET_ROWS * 64 : 1];
@@ -309,9 +317,11 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
     // ---- one batch of loads -------------------------------------------------------------
     const uint32_t *ctr_row = p.ctr + base;
     const float *st_row = p.state + base;
-    const float *act_row = p.actions + base;
+    const act_t *act_row;
+    if constexpr (ACT64) act_row = p.actions64 + base; else act_row = p.actions + base;
     uint32_t ctr = NIG_CTR_DONE;
-    float s[S], a[A], n[S];
+    float s[S], n[S];
+    act_t a[A];
     using nz_t = std::conditional_t<PARITY, double, typename Env::fast_noise_t>;   // injected draws are fp64
     nz_t nz[KSN];
     if (in_range) {
@@ -329,7 +339,7 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = 0.0f;
+        for (int k = 0; k < A; ++k) a[k] = (act_t)0;
         if constexpr (PARITY && KS > 0) {
 #pragma unroll
             for (int k = 0; k < KS; ++k) nz[k] = 0.0;
@@ -357,7 +367,7 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
 
     // ---- IndustrialEnv.step in registers --------------------------------------------------
     const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
-    StepResult<Env> res;
+    StepResult<Env, reward_of<Env, act_t>> res;
     step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
 
     const int step = step_pre + 1;
@@ -372,7 +382,7 @@ __global__ void __launch_bounds__(BLOCK, Env::STEP_WAVES) step_kernel(const Step
         double ret = 0.0;
         if (p.tally) {                            // utils.py:99  episode_return += reward
             const double prev = (p.ep_ret + base)[tid];
-            if constexpr (Env::RET_F32) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR)
+            if constexpr (Env::RET_F32 && !ACT64) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR, float32 rewards)
             else ret = prev + (double)res.reward;
         }
         if (done) {
@@ -1301,6 +1311,7 @@ namespace nig {
 
 struct EnvLaunch {
     void (*step)(const StepArgs &, bool parity, unsigned grid, hipStream_t);
+    void (*step64)(const StepArgs &, bool parity, unsigned grid, hipStream_t);   // float64 action rows; nullptr: the env takes float32
     void (*rollout)(int out_mode, const RolloutArgs &, uint32_t t0, unsigned grid, hipStream_t);
     void (*policy)(const PolicyArgs &, unsigned grid, hipStream_t);
     void (*mlp)(const MlpArgs &, unsigned grid, hipStream_t);      // nullptr: env shape not supported by the MFMA actor
@@ -1328,6 +1339,15 @@ static void launch_step(const StepArgs &a, bool parity, unsigned grid, hipStream
 {
     if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
+}
+
+template <class Env>
+static void launch_step64(const StepArgs &a, bool parity, unsigned grid, hipStream_t st)
+{
+    if constexpr (Env::HAS_ACT64) {
+        if (parity) hipLaunchKernelGGL((step_kernel<Env, true, true>), dim3(grid), dim3(BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((step_kernel<Env, false, true>), dim3(grid), dim3(BLOCK), 0, st, a);
+    }
 }
 
 template <class Env, bool PAIRED, bool FULL>
@@ -1385,7 +1405,7 @@ static void launch_fill(float *act, int64_t ld_act, int64_t B, uint64_t env0, ui
 template <class Env>
 static const EnvLaunch *env_launch_table()
 {
-    static const EnvLaunch T = {launch_step<Env>, launch_rollout_env<Env>, launch_policy<Env>,
+    static const EnvLaunch T = {launch_step<Env>, Env::HAS_ACT64 ? launch_step64<Env> : nullptr, launch_rollout_env<Env>, launch_policy<Env>,
                                 (Env::S % 2 == 0 && Env::A <= 8) ? launch_mlp<Env> : nullptr,
                                 launch_reset<Env>, launch_fill<Env>};
     return &T;

@@ -56,9 +56,11 @@ class IndustrialEnv:
         self._C = C
         self._st_buf = np.zeros((self.state_dim, 1), dtype=np.float32)
         self._act_buf = np.zeros((self.action_dim, 1), dtype=np.float32)
+        self._act64_buf = np.zeros((self.action_dim, 1), dtype=np.float64)
         self._rew_buf = np.zeros(1, dtype=np.float64)
         self._fl_buf = np.zeros(1, dtype=np.uint32)
         self._p_st, self._p_act = self._st_buf.ctypes.data_as(C.c_void_p), self._act_buf.ctypes.data_as(C.c_void_p)
+        self._p_act64 = self._act64_buf.ctypes.data_as(C.c_void_p)
         self._p_rew, self._p_fl = self._rew_buf.ctypes.data_as(C.c_void_p), self._fl_buf.ctypes.data_as(C.c_void_p)
 
     # -- per-env host pieces (overridden) --------------------------------------
@@ -119,8 +121,11 @@ class IndustrialEnv:
         if self.done or self._needs_reset:
             raise RuntimeError("Environment is done. Call reset() first.")
         action = np.asarray(action)
-        a32 = action.astype(np.float32, copy=False).reshape(self.action_dim)
-        a_clip = a32 if self._no_clip else np.clip(a32, self.action_space.low, self.action_space.high)   # base.py:167
+        # base.py:163-167 clips without casting: a float64 action vector (what get_dataset and the baseline agents
+        # build) makes NumPy evaluate the action-dependent arithmetic in float64 -> nig_step_host64 follows that
+        act64 = action.dtype == np.float64
+        a_in = action.reshape(self.action_dim) if act64 else action.astype(np.float32, copy=False).reshape(self.action_dim)
+        a_clip = a_in if self._no_clip else np.clip(a_in, self.action_space.low, self.action_space.high)   # base.py:167
         state_pre = self.state
         mask = self._sync_constraint_mask()
         custom = self._custom
@@ -130,13 +135,22 @@ class IndustrialEnv:
             sn = self._draw_step_noise()
             sn = None if sn is None else np.ascontiguousarray(sn, dtype=np.float64)
         # one call: upload action (+ noise), step kernel, download state / reward / flag word, one sync
-        self._act_buf[:, 0] = a32
-        _lib.check(self._b._L.nig_step_host(self._b._h, self._p_act, None if sn is None else sn.ctypes.data_as(self._C.c_void_p),
-                                            self._p_st, self._p_rew, self._p_fl, None))
+        sn_p = None if sn is None else sn.ctypes.data_as(self._C.c_void_p)
+        if act64:
+            self._act64_buf[:, 0] = a_in
+            _lib.check(self._b._L.nig_step_host64(self._b._h, self._p_act64, sn_p, self._p_st, self._p_rew, self._p_fl, None))
+        else:
+            self._act_buf[:, 0] = a_in
+            _lib.check(self._b._L.nig_step_host(self._b._h, self._p_act, sn_p, self._p_st, self._p_rew, self._p_fl, None))
         new_state = self._st_buf[:, 0].copy()
         flags = int(self._fl_buf[0])
         reward64 = float(self._rew_buf[0])
-        reward: Any = f32(reward64) if int(self._b.spec.reward_is_f32) else reward64
+        # reward type as upstream: np.float32 while everything was float32 (CR, build-specified plants), np.float64 once a
+        # float64 action took part (CR: np.float32 - np.float64), a Python float where the env returns float(...)
+        if int(self._b.spec.reward_is_f32):
+            reward: Any = (np.float64(reward64) if act64 and self.ENV_ID == "ChemicalReactor-v0" else f32(reward64))
+        else:
+            reward = reward64
 
         nv = ((flags >> _lib.FLAG_NVIOL_SHIFT) & 3) + ((flags >> 13) & 1) * 4
         nc = (flags >> _lib.FLAG_NCRIT_SHIFT) & 3

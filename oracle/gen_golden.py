@@ -11,7 +11,11 @@ Fixture families:
   <env>_g2.npz  teacher-forced threshold / edge cases (one ulp either side of constants)
   <env>_g3.npz  full rollouts (ragged, concatenated) with per-step outputs + episode sums
   <env>_g4.npz  evaluate_with_safety() result dict for a fixed stub agent + its noise
-Reference semantics pinned: NumPy 2.2.6, float32 actions.
+  <env>_g5.npz  the G1 inputs with the action handed over as float64 (float32-valued)     [arg: g5]
+  <env>_g6.npz  the G1 states stepped with genuine float64 action values                  [arg: g6]
+  datasets.npz  env.get_dataset(quality) under np.random.seed(123): heads + summaries      [arg: datasets]
+  baseline_agents.npz  act() sequences of benchmarks/baseline_agents.py on recorded obs   [arg: agents]
+Reference semantics pinned: NumPy 2.2.6; float32 actions (G1-G4) and float64 actions (G5, G6, datasets).
 """
 import json
 import math
@@ -595,8 +599,11 @@ def main():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("datasets", "g5")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("datasets", "g5", "g6", "agents")):
     main()
+
+
+HEAD = 900     # transitions kept per dataset: > 2 ChemicalReactor episodes, ~150 PowerGrid, ~450 RobotAssembly episodes
 
 
 def gen_dataset_fixtures():
@@ -604,7 +611,7 @@ def gen_dataset_fixtures():
     utils = load_reference()
     out = {}
     for key, name in ENVS.items():
-        for q in (("expert",) if key == "cr" else ("expert", "random", "mixed")):
+        for q in (("expert", "medium") if key == "cr" else ("expert", "random", "mixed")):
             env = utils.make(name)
             np.random.seed(123)
             d = env.get_dataset(q)
@@ -613,7 +620,7 @@ def gen_dataset_fixtures():
             out[f"{key}_{q}_reward_mean"] = np.array(float(d["rewards"].astype(np.float64).mean()))
             out[f"{key}_{q}_n_terminals"] = np.array(int(d["terminals"].sum()))
             for k in ("observations", "actions", "rewards", "terminals"):
-                out[f"{key}_{q}_{k}"] = d[k][:160]
+                out[f"{key}_{q}_{k}"] = d[k][:HEAD]
             print(key, q, n, float(d["rewards"].mean()), int(d["terminals"].sum()))
     np.savez_compressed(os.path.join(OUT, "datasets.npz"), **out)
 
@@ -658,3 +665,96 @@ def gen_g5():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g5":
     gen_g5()
+
+
+def gen_g6():
+    """G6: the G1 states and noise again, stepped with GENUINE float64 action values (not float32-representable):
+    the arithmetic the reference really performs for its own callers (get_dataset, baseline agents).  A third of
+    the rows lie beyond the clip bounds.  Stored: the float64 actions and the reference's outputs."""
+    utils = load_reference()
+    rng = np.random.Generator(np.random.PCG64(66))
+    for key, name in ENVS.items():
+        d = dict(np.load(os.path.join(OUT, f"{key}_g1.npz")))
+        n = min(1500, len(d["reward"]))
+        env = utils.make(name)
+        K = d["noise"].shape[1]
+        log = StepLog(env.state_dim, env.action_dim, K)
+        a64_rows = []
+        with NoiseTap(6) as tap:
+            env.reset(); tap.take()
+            for i in range(n):
+                force(env, d["state_pre"][i], int(d["step_pre"][i]), int(d["viol_pre"][i]))
+                tap.forced = list(d["noise"][i])
+                a64 = d["action"][i].astype(np.float64) * (1.3 if i % 3 == 0 else 0.9) + rng.normal(0.0, 1e-3, env.action_dim)
+                assert a64.dtype == np.float64
+                state_pre = env.state.copy()
+                bits = constraint_bits(env, state_pre, a64)
+                tap.take()
+                obs, reward, term, trunc, info = env.step(a64)
+                noise = tap.take(); tap.forced = None
+                sm = info["safety_metrics"]
+                a64_rows.append(a64.copy())
+                log.add(state_pre=state_pre, action=a64.astype(f32), noise=noise, step_pre=int(d["step_pre"][i]),
+                        viol_pre=int(d["viol_pre"][i]), state_next=obs.copy(), reward=float(reward),
+                        terminated=int(bool(term)), truncated=int(bool(trunc)), viol=sm.violation_count,
+                        crit=sm.critical_violations, bits=bits, violations_after=info["violations"])
+        arr = log.arrays()
+        arr["action64"] = np.asarray(a64_rows, dtype=np.float64)
+        arr["reward_is_float64"] = np.array(isinstance(reward, (float, np.float64)) and not isinstance(reward, np.float32))
+        np.savez_compressed(os.path.join(OUT, f"{key}_g6.npz"), **arr)
+        print(key, "g6", n, "reward type", type(reward).__name__)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g6":
+    gen_g6()
+
+
+def load_baseline_agents():
+    """benchmarks/baseline_agents.py is NumPy-only; benchmarks/__init__ pulls modules that need scipy/jax, so it
+    is bypassed with a shell package exactly like the root package."""
+    import importlib
+    import types
+    load_reference()
+    if "neorl_industrial.benchmarks" not in sys.modules:
+        shell = types.ModuleType("neorl_industrial.benchmarks")
+        shell.__path__ = ["/root/reference/src/neorl_industrial/benchmarks"]
+        sys.modules["neorl_industrial.benchmarks"] = shell
+    return importlib.import_module("neorl_industrial.benchmarks.baseline_agents")
+
+
+def gen_agents():
+    """act() sequences of the reference's baseline agents (benchmarks/baseline_agents.py:28-114) on recorded
+    observations: Constant, MPC (proportional), PID (with its never-reset integral) and Random (draws recorded).
+    Stored per env: the observation sequence (from the G3 rollouts, episode after episode, so the PID memory
+    runs across episode boundaries as it does upstream) and every agent's action sequence."""
+    ba = load_baseline_agents()
+    out = {}
+    for key, name in ENVS.items():
+        g3 = dict(np.load(os.path.join(OUT, f"{key}_g3.npz")))
+        obs = g3["obs"][:600].astype(f32)                       # [n, S] float32 observations as env.step returns them
+        S, A = obs.shape[1], g3["action"].shape[1]
+        setpoint = np.linspace(0.1, 0.5, A)
+        agents = {
+            "constant": ba.ConstantAgent(S, A, constant_action=np.linspace(-0.3, 0.4, A)),
+            "mpc": ba.MPC_Agent(S, A),
+            "pid": ba.PIDControllerAgent(S, A, kp=0.02, ki=0.001, kd=0.01, setpoint=setpoint),
+        }
+        out[f"{key}_obs"] = obs
+        out[f"{key}_pid_setpoint"] = setpoint
+        out[f"{key}_constant_action"] = np.linspace(-0.3, 0.4, A)
+        for aname, ag in agents.items():
+            acts = np.stack([np.asarray(ag.act(o)) for o in obs])
+            out[f"{key}_{aname}_actions"] = acts
+            out[f"{key}_{aname}_dtype"] = np.array(str(acts.dtype))
+        rnd = ba.RandomAgent(S, A, action_low=-1.0, action_high=1.0)
+        with NoiseTap(17) as tap:
+            acts = np.stack([np.asarray(rnd.act(o)) for o in obs[:64]])
+            draws = tap.take()
+        out[f"{key}_random_actions"] = acts
+        out[f"{key}_random_draws"] = draws.reshape(64, A)
+        print(key, {k: str(v.dtype) for k, v in out.items() if k.startswith(key) and k.endswith("actions")})
+    np.savez_compressed(os.path.join(OUT, "baseline_agents.npz"), **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "agents":
+    gen_agents()

@@ -809,6 +809,256 @@ void oracle_step(int env, const float *state, const float *action_raw, const dou
     out->shutdown = crit > 0;
 }
 
+/* ------------------------------------------------------------------------------
+ * FLOAT64 ACTIONS.  The reference's own callers hand np.float64 arrays to step() (get_dataset:
+ * chemical_reactor.py:364-393, power_grid.py:216-233, robot_assembly.py:266-290; baseline agents:
+ * benchmarks/baseline_agents.py:28-114), and base.py:167 clips without casting (np.clip of a float64
+ * array against float32 bounds stays float64).  Under NumPy >= 2 every expression that touches an
+ * action element is then float64, and float64 spreads through what depends on it until a value is
+ * stored into the float32 state vector.  Restated per env below; pinned by tests/golden/<env>_g5.npz
+ * (float32-valued float64 actions) and <env>_g6.npz (genuine float64 action values).
+ * ---------------------------------------------------------------------------- */
+static double det_exp64(double x);      /* fdlibm-style e^x (MATH_POLY), below */
+static double o_exp64(double x, int flavor) { return flavor == MATH_POLY ? det_exp64(x) : exp(x); }
+
+/* chemical_reactor.py:109-226 with a float64 action vector */
+static void cr_dynamics64(const float *s, const double *a, const double *noise, int flavor, float *o)
+{
+    float temp = s[0], pressure = s[1], cool = s[2], feed = s[3], conc = s[4], cat = s[5];
+    float hx = s[6], relief = s[7], estop = s[8], alarm = s[9], level = s[10], bt = s[11];
+    if (!(estop < 0.5f)) {              /* emergency branch :131-134: the action is not read, everything stays float32 */
+        const float zero[3] = {0.0f, 0.0f, 0.0f};
+        cr_dynamics(s, zero, noise, flavor, o);
+        return;
+    }
+    double hp = a[0] * 50000.0, cadj = a[1] * 0.1, fadj = a[2] * 0.1;           /* :127-129 float64 */
+    float kc = (0.1f * conc) * (cat / 100.0f);                                   /* :137-139 float32 */
+    float rh = kc * 10000.0f;
+    float ch = ((cool * 100.0f) * (temp - hx)) * 0.1f;                           /* :141 float32 */
+    double dT = ((hp + (double)rh) - (double)ch) / 418000.0;                     /* :143-146 */
+    dT = dT + noise[0];                                                          /* :149 */
+    double nT = (double)temp + dT * 0.1;                                         /* :151 */
+    double pft = (double)pressure * (nT / (double)temp);                         /* :155 */
+    float pfr = (conc * 0.1f) * 1000.0f;                                         /* :156 float32 */
+    double nP = pft + (double)(pfr * 0.1f);                                      /* :158 */
+    nP = nP + noise[1];                                                          /* :159 */
+    double nrel = pymaxd(0.0, pymind(100.0, (double)relief + (nP - 506625.0) * 0.001));   /* :162-163 */
+    if (nrel > 0.0) nP = pymaxd(101325.0, nP - (nrel * 0.01) * 10000.0);         /* :166-168 */
+    double ncool = pymaxd(10.0, pymind(100.0, (double)cool + cadj));             /* :171 */
+    double nfeed = pymaxd(5.0, pymind(50.0, (double)feed + fadj));               /* :172 */
+    double rr = (double)kc * o_exp64((-(nT - 320.0)) / 20.0, flavor);            /* :175-178 np.exp on a float64 scalar */
+    double fd = nfeed * 0.001;                                                   /* :180 */
+    double nconc = pymaxd(0.0, (double)conc + (rr - fd) * 0.1);                  /* :181-182 */
+    float deact = (nT > 340.0) ? 0.001f : 0.0001f;                               /* :185 */
+    float ncat = pymaxf(50.0f, cat - deact);                                     /* :186 float32 */
+    float nhx = hx + (0.1f * ((290.0f + cool * 0.1f) - hx)) * 0.1f;              /* :189-190 float32 (old cooling flow) */
+    float nestop = estop, nalarm = alarm;
+    if (nT > 345.0 || nP > 480000.0) nalarm = 1.0f;                              /* :196-197 */
+    if (nT > 350.0 || nP > 506625.0) { nestop = 1.0f; nalarm = 1.0f; }           /* :199-201 */
+    double lc = (nfeed - 20.0) * 0.1;                                            /* :204 */
+    double nlevel = pymaxd(0.0, pymind(100.0, (double)level + lc * 0.1));        /* :205 */
+    o[0] = (float)nT; o[1] = (float)nP; o[2] = (float)ncool; o[3] = (float)nfeed; o[4] = (float)nconc;
+    o[5] = ncat; o[6] = nhx; o[7] = (float)nrel; o[8] = nestop; o[9] = nalarm; o[10] = (float)nlevel;
+    o[11] = bt + 0.1f;                                                           /* :208-224 np.array(..., dtype=float32) */
+}
+
+/* chemical_reactor.py:228-270: float32 until the action penalty, float64 from there */
+static double cr_reward64(const float *n, const double *a)
+{
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    float r = cr_reward(n, zero);                              /* ... - 0.0f * 0.1f leaves r as it was */
+    double ap = ((0.0 + fabs(a[0])) + fabs(a[1])) + fabs(a[2]);
+    return (double)r - ap * 0.1;                               /* :268-269 */
+}
+
+/* power_grid.py:24-30 with a float64 action */
+static void pg_checks64(const float *s, const double *a, int *ok)
+{
+    const float zero[8] = {0};
+    pg_checks(s, zero, ok);
+    int g = 1;
+    for (int i = 0; i < 8; i++) {
+        double ng = (double)s[9 + i] + a[i];
+        if (!(ng >= 0.0 && ng <= 100.0)) g = 0;
+    }
+    ok[2] = g;
+}
+
+/* power_grid.py:112-153 with a float64 action */
+static void pg_dynamics64(const float *s, const double *a, const double *noise, double dt, float *o)
+{
+    const float zero[8] = {0};
+    pg_dynamics(s, zero, noise, dt, o);                        /* voltages, loads, line flows do not see the action */
+    double ngen[8];
+    for (int i = 0; i < 8; i++) {                              /* :124 np.clip(gen + a, 0, 100) in float64 */
+        double g = (double)s[9 + i] + a[i];
+        g = (g < 0.0) ? 0.0 : g;
+        g = (g > 100.0) ? 100.0 : g;
+        ngen[i] = g;
+    }
+    double tg = sum8d(ngen);                                   /* :127 */
+    float tl = sum8f(&s[17]);                                  /* :128 float32 */
+    double imb = tg - (double)tl;                              /* :129 */
+    double fd = ((double)(-1.0f * s[0]) + imb) / 5.0;          /* :132  (-D * f) is float32, the sum float64 */
+    double nf = (double)s[0] + fd * dt;                        /* :133 */
+    o[0] = (float)nf;
+    for (int i = 0; i < 8; i++) o[9 + i] = (float)ngen[i];
+}
+
+/* power_grid.py:155-177 with a float64 action */
+static double pg_reward64(const float *n, const double *a)
+{
+    const float zero[8] = {0};
+    double base = pg_reward(n, zero);                          /* ((fr + vr) + er) + (-5.0f * 0) : adding -0.0 changes nothing */
+    double a2[8];
+    for (int i = 0; i < 8; i++) a2[i] = a[i] * a[i];
+    double ap = -5.0 * sum8d(a2);                              /* :173 */
+    return base + ap;                                          /* :175 */
+}
+
+/* robot_assembly.py:139-188 with a float64 action */
+static void ra_dynamics64(const float *s, const double *a, double dt, int flavor, float *o)
+{
+    /* the float32 form with q = joint + a*dt taken in float64 (:148): rebuild through a scratch state whose
+       joints already are the float64 sums is not possible in float32, so the body is restated */
+    double q[7], p[3];
+    for (int i = 0; i < 7; i++) {
+        double d = (double)s[7 + i] + a[i] * dt;               /* :148 float64 */
+        d = (d < -RA_PI) ? -RA_PI : d;
+        d = (d > RA_PI) ? RA_PI : d;
+        q[i] = d;
+    }
+    ra_fk(q, flavor, p);
+    double v[3];
+    for (int i = 0; i < 3; i++) v[i] = (p[i] - (double)s[i]) / dt;
+    double dx = p[0] - RA_TGT[0], dy = p[1] - RA_TGT[1], dz = p[2] - RA_TGT[2];
+    double dist = sqrt(dx * dx + dy * dy + dz * dz);
+    double F[3] = {0.0, 0.0, 0.0};
+    if (dist < 0.01) {
+        double nf = pymaxd(0.0, 0.01 - dist) * 1000.0;
+        F[2] = 0.0 - nf;
+        if (nf == 0.0) F[2] = 0.0;
+    }
+    double ae = sqrt(dx * dx + dy * dy);
+    double align = pymaxd(0.0, 1.0 - ae / 0.005);
+    double ins = pymaxd(0.0, RA_TGT[2] - p[2]);
+    double depth = pymind(1.0, ins / 0.05);
+    double compl = align * depth;
+    memcpy(o, s, 24 * sizeof(float));
+    o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2];
+    o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f;
+    for (int i = 0; i < 7; i++) o[7 + i] = (float)q[i];
+    o[14] = (float)v[0]; o[15] = (float)v[1]; o[16] = (float)v[2]; o[17] = 0.0f;
+    o[18] = (float)F[0]; o[19] = (float)F[1]; o[20] = (float)F[2];
+    o[21] = (float)align; o[22] = (float)depth; o[23] = (float)compl;
+}
+
+/* robot_assembly.py:190-222 with a float64 action */
+static double ra_reward64(const float *n, const double *a)
+{
+    float cr = 100.0f * n[23];
+    double dx = (double)n[0] - RA_TGT[0], dy = (double)n[1] - RA_TGT[1], dz = (double)n[2] - RA_TGT[2];
+    double dr = -10.0 * sqrt(dx * dx + dy * dy + dz * dz);
+    float fm = sqrtf(n[18] * n[18] + n[19] * n[19] + n[20] * n[20]);
+    double ap = 0.0;
+    float vp = 0.0f;
+    for (int i = 0; i < 7; i++) ap = ap + a[i] * a[i];         /* :211 float64, sequential (n < 8) */
+    ap = -0.1 * ap;
+    for (int i = 0; i < 4; i++) vp = vp + n[14 + i] * n[14 + i];
+    vp = -0.5f * vp;
+    double tot = (double)cr + dr;
+    if (fm > 30.0f) tot = tot + (double)(-50.0f * (fm - 30.0f)); else tot = tot + 0.0;
+    tot = tot + ap;
+    tot = tot + (double)vp;
+    return tot;
+}
+
+/* IndustrialEnv.step with a float64 action vector.  Envs other than the three NumPy ones convert the action to
+ * float32 themselves (the Advanced envs are JAX with x64 off; the build-specified plants are float32 by design). */
+void oracle_step64(int env, const float *state, const double *action_raw, const double *noise,
+                   int step_pre, int max_steps, double dt, int flavor, float *next, oracle_step_out_t *out)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    if (env != ORACLE_CR && env != ORACLE_PG && env != ORACLE_RA) {
+        float a32[10];
+        for (int i = 0; i < sp->action_dim; i++) a32[i] = (float)action_raw[i];
+        oracle_step(env, state, a32, noise, step_pre, max_steps, dt, flavor, next, out);
+        return;
+    }
+    double a[10];
+    for (int i = 0; i < sp->action_dim; i++) {                 /* base.py:167: float64 array, float32 bounds -1, 1 */
+        double x = action_raw[i];
+        x = (x < -1.0) ? -1.0 : x;
+        x = (x > 1.0) ? 1.0 : x;
+        a[i] = x;
+    }
+    int ok[3];
+    const float zero[10] = {0};
+    if (env == ORACLE_CR) cr_checks(state, zero, ok);
+    else if (env == ORACLE_PG) pg_checks64(state, a, ok);
+    else ra_checks(state, zero, ok);
+    int viol = 0, crit = 0;
+    for (int k = 0; k < 3; k++) if (!ok[k]) { viol++; if (sp->critical[k]) crit++; }
+    double r;
+    if (env == ORACLE_CR) { cr_dynamics64(state, a, noise, flavor, next); r = cr_reward64(next, a); }
+    else if (env == ORACLE_PG) { pg_dynamics64(state, a, noise, dt, next); r = pg_reward64(next, a); }
+    else { ra_dynamics64(state, a, dt, flavor, next); r = ra_reward64(next, a); }
+    for (int k = 0; k < 3; k++) if (!ok[k]) r = r + sp->penalty[k];      /* base.py:179-183 (float64 reward) */
+    if (crit > 0) r = r - 1000.0;
+    int step = step_pre + 1;
+    int term = (env == ORACLE_CR) ? cr_done(next) : (env == ORACLE_PG) ? pg_done(next) : ra_done(next);
+    int trunc = step >= max_steps;
+    if (crit > 0) term = 1;
+    out->reward = r; out->terminated = term; out->truncated = trunc;
+    out->violation_count = viol; out->critical_violations = crit;
+    for (int k = 0; k < 3; k++) out->ok[k] = ok[k];
+    out->viol_mask = (!ok[0] ? 1 : 0) | (!ok[1] ? 2 : 0) | (!ok[2] ? 4 : 0);
+    out->shutdown = crit > 0;
+}
+
+void oracle_step_batch64(int env, int n, const float *states, const double *actions, const double *noise,
+                         const int *step_pre, int max_steps, double dt, int flavor,
+                         float *next, double *reward, int *term, int *trunc, int *viol, int *crit, int *ok, int *mask)
+{
+    const oracle_spec_t *sp = &SPECS[env];
+    for (int i = 0; i < n; i++) {
+        oracle_step_out_t o;
+        oracle_step64(env, states + (size_t)i * sp->state_dim, actions + (size_t)i * sp->action_dim,
+                      noise ? noise + (size_t)i * sp->k_step : NULL, step_pre[i], max_steps, dt, flavor,
+                      next + (size_t)i * sp->state_dim, &o);
+        reward[i] = o.reward; term[i] = o.terminated; trunc[i] = o.truncated;
+        viol[i] = o.violation_count; crit[i] = o.critical_violations;
+        for (int k = 0; k < 3; k++) ok[i * 3 + k] = o.ok[k];
+        if (mask) mask[i] = o.viol_mask | (o.shutdown << 8);
+    }
+}
+
+/* e^x in double: Cody-Waite by ln2 (hi/lo), fdlibm's degree-5 kernel on r^2, exact scaling.  Stands in for
+ * np.exp on a float64 scalar (chemical_reactor.py:177 with a float64 action); < 1 ulp. */
+static double det_exp64(double x)
+{
+    if (x != x) return x;
+    if (x > 709.78) return INFINITY;
+    if (x < -745.13) return 0.0;
+    const double k = floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double hi = fma(-k, 6.93147180369123816490e-01, x);
+    const double lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    double c = 4.13813679705723846039e-08;
+    c = fma(c, t, -1.65339022054652515390e-06);
+    c = fma(c, t, 6.61375632143793436117e-05);
+    c = fma(c, t, -2.77777777770155933842e-03);
+    c = fma(c, t, 1.66666666666666019037e-01);
+    c = r - t * c;
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    int ki = (int)k;
+    const int k1 = ki / 2, k2 = ki - k1;                      /* two exact power-of-two scalings */
+    union { uint64_t u; double d; } s1, s2;
+    s1.u = (uint64_t)(k1 + 1023) << 52; s2.u = (uint64_t)(k2 + 1023) << 52;
+    return (y * s1.d) * s2.d;
+}
+
 /* batched convenience for tests: row-major [n][S] states etc. */
 void oracle_step_batch(int env, int n, const float *states, const float *actions, const double *noise,
                        const int *step_pre, int max_steps, double dt, int flavor,
