@@ -433,6 +433,19 @@ int nig_get_safety_metrics(nig_handle *h, const uint32_t *flags, int32_t *out, i
  */
 int nig_reduce_tally(nig_handle *h, double *partial_out, void *stream);
 
+/*
+ * The path's one exchange (BASELINE north_star: "an RCCL all-reduce over xGMI only for the final return /
+ * safety-violation reduction"), for hosts that do not go through torch.distributed: reduce the tallies of this
+ * rank's handles (one, or the segments of a mixed batch) to one partial vector, ncclAllGather the partial vectors
+ * of all ranks of `comm` (an ncclComm_t the caller created, one rank per GPU; NULL = single process, no collective)
+ * and combine them in RANK ORDER on every rank: sums as fixed-order fp64 additions, exact integer counts, min / max
+ * rows -- bit-identical on all ranks.  The 13 aggregates of evaluate_with_safety (utils.py:128-152) follow from
+ * `out` (DEVICE double [NIG_T_ROWS]).  `scratch`: DEVICE doubles, at least (n_handles + 1 + ranks) * NIG_T_ROWS.
+ * RCCL is taken from the copy already loaded in the process (dlsym), else librccl.so is dlopen'ed.
+ */
+int nig_reduce_metrics(nig_handle *const *handles, int32_t n_handles, void *nccl_comm, double *scratch,
+                       int64_t scratch_doubles, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,7 +98,7 @@ def build(force=False, verbose=False, jobs=None):
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile_one(hipcc, s, hdr_hash, verbose), srcs))
     tmp = f"{LIB}.tmp.{os.getpid()}"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

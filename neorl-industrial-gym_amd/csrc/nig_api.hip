@@ -1,5 +1,7 @@
 // nig_api.hip -- C ABI of libnig.so (include/nig.h) and the environment-independent kernels.
 // The per-environment kernels are instantiated in env_*.hip and reached through nig::EnvLaunch.
+#include <dlfcn.h>
+
 #include "nig_kernels.hpp"
 
 namespace nig {
@@ -84,6 +86,20 @@ __global__ void __launch_bounds__(BLOCK) narrow_rows_kernel(const double *src, i
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
     for (int k = 0; k < rows; ++k) dst[(int64_t)k * ld_dst + i] = (float)src[(int64_t)k * ld_src + i];
+}
+
+// combine `n` partial tally vectors [n][NIG_T_ROWS] in index order: sums, min / max rows (one thread per row)
+__global__ void combine_partials_kernel(const double *parts, int n, double *out)
+{
+    const int r = threadIdx.x;
+    if (r >= NIG_T_ROWS) return;
+    const bool is_min = (r == NIG_T_RET_MIN), is_max = (r == NIG_T_RET_MAX);
+    double acc = is_min ? __builtin_inf() : (is_max ? -__builtin_inf() : 0.0);
+    for (int b = 0; b < n; ++b) {
+        const double v = parts[(int64_t)b * NIG_T_ROWS + r];
+        acc = is_min ? fmin(acc, v) : (is_max ? fmax(acc, v) : acc + v);
+    }
+    out[r] = acc;
 }
 
 __global__ void __launch_bounds__(BLOCK) copy_rows_kernel(const float *src, int64_t ld_src, float *dst, int64_t ld_dst,
@@ -977,6 +993,62 @@ int nig_mixed_rollout(nig_mixed *m, int32_t n_steps, const float *action_ring, i
     if (!m) return fail(NIG_ERR_INVALID, "nig_mixed_rollout: NULL handle%s");
     return nig_rollout_mixed(m->seg, m->off, m->n, n_steps, action_ring, m->ld, slot_stride, ring_len, reward_out, flags_out,
                              out_stride, stream);
+}
+
+// ---- the path's one collective: all-gather of the partial tallies over RCCL ----------------------
+// RCCL is resolved at run time from whatever copy the process already holds (a PyTorch process has its own
+// librccl.so; a plain C host links or loads /opt/rocm/lib/librccl.so): a communicator is only meaningful to the
+// library instance that created it, so libnig.so must not bring a second one.
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_count_fn)(void *, int *);
+static bool rccl_resolve(nccl_allgather_fn *ag, nccl_count_fn *cnt)
+{
+    static nccl_allgather_fn s_ag = nullptr;
+    static nccl_count_fn s_cnt = nullptr;
+    if (!s_ag) {
+        void *f = dlsym(RTLD_DEFAULT, "ncclAllGather"), *c = dlsym(RTLD_DEFAULT, "ncclCommCount");
+        if (!f || !c) {
+            void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) { f = dlsym(lib, "ncclAllGather"); c = dlsym(lib, "ncclCommCount"); }
+        }
+        s_ag = (nccl_allgather_fn)f; s_cnt = (nccl_count_fn)c;
+    }
+    *ag = s_ag; *cnt = s_cnt;
+    return s_ag && s_cnt;
+}
+
+int nig_reduce_metrics(nig_handle *const *handles, int32_t n_handles, void *comm, double *scratch, int64_t scratch_doubles,
+                       double *out, void *stream)
+{
+    if (!handles || n_handles <= 0 || !scratch || !out) return fail(NIG_ERR_INVALID, "nig_reduce_metrics: NULL argument%s");
+    int world = 1;
+    nccl_allgather_fn allgather = nullptr;
+    nccl_count_fn count = nullptr;
+    if (comm) {
+        if (!rccl_resolve(&allgather, &count)) return fail(NIG_ERR_UNSUPPORTED, "nig_reduce_metrics: RCCL (librccl.so) not found in this process%s");
+        if (count(comm, &world) != 0 || world <= 0) return fail(NIG_ERR_INVALID, "nig_reduce_metrics: ncclCommCount failed%s");
+    }
+    // scratch: [n_handles][ROWS] local partials | [ROWS] this rank's partial | [world][ROWS] gathered
+    const int64_t need = ((int64_t)n_handles + 1 + world) * NIG_T_ROWS;
+    if (scratch_doubles < need) return fail(NIG_ERR_INVALID, "nig_reduce_metrics: scratch smaller than (n_handles + 1 + ranks) * NIG_T_ROWS doubles%s");
+    hipStream_t st = (hipStream_t)stream;
+    double *local = scratch, *mine = scratch + (int64_t)n_handles * NIG_T_ROWS, *all = mine + NIG_T_ROWS;
+    for (int k = 0; k < n_handles; ++k) {
+        const int rc = nig_reduce_tally(handles[k], local + (int64_t)k * NIG_T_ROWS, stream);
+        if (rc != NIG_OK) return rc;
+    }
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(1), dim3(64), 0, st, (const double *)local, n_handles, mine);
+    if (comm) {
+        // ncclAllGather (RCCL; over xGMI between the GPUs of a node): NIG_T_ROWS doubles per rank, rank order
+        if (allgather(mine, all, (size_t)NIG_T_ROWS, /*ncclDouble*/ 8, comm, st) != 0)
+            return fail(NIG_ERR_HIP, "nig_reduce_metrics: ncclAllGather failed%s");
+        hipLaunchKernelGGL(combine_partials_kernel, dim3(1), dim3(64), 0, st, (const double *)all, world, out);
+    } else {
+        hipLaunchKernelGGL(combine_partials_kernel, dim3(1), dim3(64), 0, st, (const double *)mine, 1, out);
+    }
+    HIP_TRY(hipGetLastError());
+    return NIG_OK;
 }
 
 int nig_fill_actions(nig_handle *h, uint32_t t, float *actions, int64_t ld_act, void *stream)

@@ -235,3 +235,49 @@ def test_evaluate_with_safety_on_four_condition_env(ni):
         assert got[k] == pytest.approx(want[k], rel=1e-6), k
     assert 0.0 < got["constraint_satisfaction_rate"] <= 1.0
     benv.close()
+
+
+def test_reduce_metrics_through_rccl(ni):
+    """nig_reduce_metrics: the path's one collective as a C host would call it -- the tallies of several handles
+    (here the segments of a mixed batch) reduced, all-gathered over an ncclComm_t (RCCL; a single-rank
+    communicator on this one-GPU box, created with ctypes on the RCCL copy torch already loaded) and combined in
+    rank order.  Equals the host-side combine of the per-handle partial vectors; comm = NULL skips the collective."""
+    import os
+    from neorl_industrial_gym_amd.parallel import combine_partials, metrics_from_partial
+    L, lib = ni._lib.lib(), ni._lib
+    segs = [("PowerGrid-v0", 2000), ("ChemicalReactor-v0", 1500), ("RobotAssembly-v0", 1000)]
+    mix = ni.MixedBatchedEnv(segs, seed=4, autoreset=True, tally=True)
+    ring = torch.zeros(4, mix.A_max, mix.ld, dtype=torch.float32, device=mix.device)
+    for s in range(4):
+        mix.fill_actions(20 + s, ring[s])
+    mix.reset()
+    mix.rollout(80, ring)
+    want = combine_partials(torch.stack([e.reduce_tally() for e in mix.envs])).cpu().numpy()
+    assert want[lib.T_EPISODES] > 0
+
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+
+    n = len(mix.envs)
+    hs = (C.c_void_p * n)(*[e._h for e in mix.envs])
+    scratch = torch.zeros((n + 2) * lib.T_ROWS, dtype=torch.float64, device=mix.device)
+    out = torch.zeros(lib.T_ROWS, dtype=torch.float64, device=mix.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for c in (comm, None):
+        out.zero_()
+        lib.check(L.nig_reduce_metrics(hs, n, c, C.c_void_p(scratch.data_ptr()), scratch.numel(), C.c_void_p(out.data_ptr()), st))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    m = metrics_from_partial(out)
+    assert len(m) == 13 and m["safety_violations"] == int(want[lib.T_VIOL])
+    assert L.nig_reduce_metrics(hs, n, comm, C.c_void_p(scratch.data_ptr()), 5, C.c_void_p(out.data_ptr()), st) == 1   # scratch too small
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    mix.close()
