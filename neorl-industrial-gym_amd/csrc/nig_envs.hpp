@@ -35,13 +35,17 @@ __device__ __forceinline__ T sum8(const T (&x)[8])
 // ChemicalReactor-v0  (environments/chemical_reactor.py), S=12 A=3, all float32
 // =================================================================================
 struct ChemicalReactor {
-    static constexpr bool COOP_RESET = false;
-    static constexpr int RESET_ROWS = 1;
+    // Only ~0.3 % of lanes finish per step, but that is a finishing lane in ~17 % of the wave-steps, and the
+    // divergent in-place reset (2 generator blocks, 8 normals, 8 fp64 initial values: ~300 instructions) then runs
+    // for one or two active lanes: ~50 instructions per wave-step on average, 14 % of the step.  Cooperative form:
+    // work item = (lane, generator block) -> four state rows through a wave-private LDS image: one short pass.
+    static constexpr bool COOP_RESET = true;
+    static constexpr int RESET_ITEMS_LOG2 = 1, RESET_ROWS = 8;
     using fast_noise_t = double;
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
-    static constexpr bool COMPACT_RESET = false;   // ~0.3 % of lanes finish per step: divergent reset is cheaper than barriers
+    static constexpr bool COMPACT_RESET = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
-    static constexpr int STEP_WAVES = 7;          // waves per SIMD the step kernel is compiled for (no spills at this cap)
+    static constexpr int STEP_WAVES = 6;          // waves per SIMD the step kernel is compiled for (no spills at this cap: 80 VGPRs)
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels (four action register sets in flight)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
@@ -69,6 +73,30 @@ struct ChemicalReactor {
         n[2] = 0.0 + 5.0 * (double)z[2];      n[3] = 0.0 + 3.0 * (double)z[3];
         n[4] = 0.0 + 0.1 * (double)z[4];      n[5] = 0.0 + 2.0 * (double)z[5];
         n[6] = 0.0 + 1.0 * (double)z[6];      n[7] = 0.0 + 5.0 * (double)z[7];
+    }
+    // One work item of a cooperative reset: generator block `blk` (0 or 1) of the lane with key `k` -> image rows
+    // 4 blk .. 4 blk + 3 = initial values of state rows {0,1,2,3} / {4,5,6,10}; same values, operation by operation,
+    // as draw_init + init.
+    __device__ static void reset_item(const RngKey &k, uint32_t blk, float *img, unsigned owner)
+    {
+        const u32x4 x = k.block(STREAM_RESET + blk);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        const bool hi = blk != 0u;
+        const double sd[4] = {hi ? 0.1 : 2.0, hi ? 2.0 : 10000.0, hi ? 1.0 : 5.0, hi ? 5.0 : 3.0};            // :93-103
+        const double mean[4] = {hi ? 0.5 : 320.0, hi ? 95.0 : 253312.5, hi ? 295.0 : 50.0, hi ? 60.0 : 30.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double n = 0.0 + sd[q] * (double)probit_normal(w[q], k.tab);
+            img[(4u * blk + (uint32_t)q) * 64u + owner] = (float)(mean[q] + n);
+        }
+    }
+    __device__ static void reset_readback(const float *img, unsigned lane, float (&s)[S])
+    {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) s[i] = img[i * 64 + lane];
+        s[7] = 0.0f; s[8] = 0.0f; s[9] = 0.0f;
+        s[10] = img[7 * 64 + lane];
+        s[11] = 0.0f;
     }
     // Two draws per step: launch counters 2k-1 and 2k share ONE Philox block (counter word t = k, words
     // 0-1 for the odd step, 2-3 for the even one; a fresh env's first step is t = 1) -- a block is ~64
@@ -308,8 +336,9 @@ struct PowerGrid {
     // blocks 6-7: uniforms u[4 (blk - 6) + q] (loads).  Block 0 also clears row 0 (freq_dev).
     // (A two-phase form with a 16-row image was tried: the rows read back in phase 0 stay live across phase 1's
     // items and pushed the rollout kernel into scratch spills: -13 %.)
-    __device__ static void reset_item(const RngKey &k, uint32_t blk, float *col)
+    __device__ static void reset_item(const RngKey &k, uint32_t blk, float *img, unsigned owner)
     {
+        float *col = img + owner;
         const bool uni = blk >= 6u;
         const u32x4 x = k.block(STREAM_RESET + (uni ? 10u + blk : blk));     // uniforms: STREAM_RESET + 16 + (blk - 6)
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -334,6 +363,12 @@ struct PowerGrid {
                 col[(17u + 4u * (blk - 6u) + (uint32_t)q) * 64u] = (float)(b * (1.0 + nn));   // :105
             }
         }
+    }
+
+    __device__ static void reset_readback(const float *img, unsigned lane, float (&n)[S])
+    {
+#pragma unroll
+        for (int k = 0; k < S; ++k) n[k] = img[k * 64 + lane];
     }
 
     // module-level check functions :10-30 (pre-state, clipped action)
@@ -471,11 +506,17 @@ struct PowerGrid {
 // RobotAssembly-v0  (environments/robot_assembly.py), S=24 A=7, fp64 internals
 // =================================================================================
 struct RobotAssembly {
-    static constexpr bool COOP_RESET = false;
-    static constexpr int RESET_ROWS = 1;
+    // ~2.4 % of lanes finish per step: ~80 % of the waves (and every block) see a reset in every step, and a reset is
+    // heavy (7 fp64 sincos).  Round 1 compacted the finishing lanes across the block behind two block barriers per
+    // step and let one wave run them; now each wave renews its own lanes cooperatively (work item = (lane, joint):
+    // uniform draw -> joint angle -> sincos -> link * cos / sin terms into a wave-private LDS image, the owner sums
+    // them in the reference's order): no block barrier, one short pass instead of a 7-sincos path.
+    static constexpr bool COOP_RESET = true;
+    static constexpr int RESET_ITEMS_LOG2 = 3;     // 7 joints (+ 1 idle item) per reset
+    static constexpr int RESET_ROWS = 29;          // image per wave: 11 rows of 64 doubles (terms) + 7 rows of 64 floats (angles)
     using fast_noise_t = double;
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;
-    static constexpr bool COMPACT_RESET = true;    // ~2.4 % of lanes per step, i.e. ~80 % of waves see a reset
+    static constexpr bool COMPACT_RESET = false;
     static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     static constexpr int STEP_WAVES = 5;
@@ -527,6 +568,47 @@ struct RobotAssembly {
         for (int i = 0; i < KR; ++i) n[i] = lo + (hi - lo) * u[i];
     }
     __device__ static void draw_step(const RngKey &, double (&)[1]) {}
+
+    // One work item of a cooperative reset: joint j of the lane with key `k` (same values, operation by operation, as
+    // draw_init + init: u_j = word j & 3 of generator block j >> 2, q_j = lo + (hi - lo) u_j, fk's link * cos / sin).
+    // Image rows of 64 doubles: 0-3 = L cos q of joints 0,2,4,6 (x); 4-7 = L sin q of joints 0,2,4,6 (z);
+    // 8-10 = L sin q of joints 1,3,5 (y); then rows of 64 floats: the 7 joint angles as stored in the state.
+    __device__ static void reset_item(const RngKey &k, uint32_t j, float *img, unsigned owner)
+    {
+        if (j >= 7u) return;
+        const u32x4 x = k.block(STREAM_RESET + (j >> 2));
+        const uint32_t sel = j & 3u;
+        const uint32_t w = sel == 0u ? x.x : (sel == 1u ? x.y : (sel == 2u ? x.z : x.w));
+        const double lo = -PI * 0.5, hi = PI * 0.5;                      // :119-120
+        const double q = lo + (hi - lo) * u01(w);
+        double sn, cs;
+        det_sincos(q, sn, cs);
+        const double L = j == 0u ? 0.3 : j == 1u ? 0.3 : j == 2u ? 0.25 : j == 3u ? 0.25 : j == 4u ? 0.15 : j == 5u ? 0.1 : 0.05;   // :85
+        double *d = reinterpret_cast<double *>(img);
+        const uint32_t h = j >> 1;
+        if (j & 1u) {
+            d[(8u + h) * 64u + owner] = L * sn;
+        } else {
+            d[h * 64u + owner] = L * cs;
+            d[(4u + h) * 64u + owner] = L * sn;
+        }
+        img[(22u + j) * 64u + owner] = (float)q;
+    }
+    __device__ static void reset_readback(const float *img, unsigned lane, float (&n)[S])
+    {
+        const double *d = reinterpret_cast<const double *>(img);
+        double x = 0.0, y = 0.0, z = 0.0;                                // fk :94-111: sequential sums in joint order
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { x += d[h * 64 + lane]; z += d[(4 + h) * 64 + lane]; }
+#pragma unroll
+        for (int h = 0; h < 3; ++h) y += d[(8 + h) * 64 + lane];
+        n[0] = (float)x; n[1] = (float)y; n[2] = (float)z;
+        n[3] = 0.0f; n[4] = 0.0f; n[5] = 0.0f; n[6] = 1.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) n[7 + i] = img[(22 + i) * 64 + lane];
+#pragma unroll
+        for (int i = 14; i < 24; ++i) n[i] = 0.0f;
+    }
 
     // module-level check functions :10-32
     __device__ static uint32_t violated(const float (&s)[S], const float (&)[A])

@@ -274,13 +274,10 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
     const int total = __popcll(m) << LOG2;
     for (int i = (int)lane; i < total; i += 64) {
         const unsigned owner = lst[i >> LOG2];
-        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)i & ((1u << LOG2) - 1u), img + owner);
+        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)i & ((1u << LOG2) - 1u), img, owner);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (mine) {
-#pragma unroll
-        for (int k = 0; k < Env::S; ++k) n[k] = img[k * 64 + lane];
-    }
+    if (mine) Env::reset_readback(img, lane, n);
 }
 
 // One launch = IndustrialEnv.step for every lane.
