@@ -45,7 +45,7 @@ struct ChemicalReactor {
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
-    static constexpr int STEP_WAVES = 6;          // waves per SIMD the step kernel is compiled for (no spills at this cap: 80 VGPRs)
+    static constexpr int STEP_BLOCK = 256, STEP_WAVES = 6;          // waves per SIMD the step kernel is compiled for (no spills at this cap: 80 VGPRs)
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels (four action register sets in flight)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
@@ -269,7 +269,7 @@ struct PowerGrid {
     // fp64 instruction when the noise is float32-valued.  Parity mode (injected fp64 draws) keeps the fp64 adds.
     using fast_noise_t = float;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
-    static constexpr int STEP_WAVES = 3;          // float32 fast-mode noise: ~115 VGPRs; the 32-row reset image allows 3 blocks per CU
+    static constexpr int STEP_WAVES = 2, STEP_BLOCK = 512;   // big batches: two 512-thread blocks per CU = 4 waves per SIMD (128 VGPRs), LDS 2 x 76 KiB
     static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }
@@ -519,7 +519,7 @@ struct RobotAssembly {
     static constexpr bool COMPACT_RESET = false;
     static constexpr bool SHARED_STEP_BLOCK = false;
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
-    static constexpr int STEP_WAVES = 5;
+    static constexpr int STEP_BLOCK = 256, STEP_WAVES = 5;
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels
     using reward_t = double;
     __device__ static constexpr float act_low(int) { return -1.0f; }
@@ -769,7 +769,7 @@ struct SpecPlant {
     static constexpr int KS = 2, KR = NP, MAX_STEPS = NIG_SPEC_MAXSTEPS[K];
     static constexpr int ROW_E = NP + A, ROW_ECUM = NP + A + 1, ROW_T = NP + A + 2;
     static constexpr bool COMPACT_RESET = false, SHARED_STEP_BLOCK = false, CUSTOM_STEP = false, RET_F32 = true;
-    static constexpr int STEP_WAVES = 4, ROLLOUT_WAVES = (S > 24) ? 2 : 3;
+    static constexpr int STEP_BLOCK = 256, STEP_WAVES = 4, ROLLOUT_WAVES = (S > 24) ? 2 : 3;
     using reward_t = float;
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -908,7 +908,7 @@ struct AdvancedChemicalReactor {
     static constexpr int ID = 3, S = 20, A = 6, KS = 0, KR = 0, MAX_STEPS = 1000;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
     static constexpr bool SHARED_STEP_BLOCK = false;
-    static constexpr int STEP_WAVES = 5;
+    static constexpr int STEP_BLOCK = 256, STEP_WAVES = 5;
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels
     using reward_t = float;    // float(total_reward) of a float32 scalar, :404
     static constexpr uint32_t CRIT_MASK = 0u;
@@ -1010,7 +1010,7 @@ struct AdvancedPowerGrid {
     static constexpr int ID = 4, S = 32, A = 8, KS = 0, KR = 0, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false, CUSTOM_STEP = true, RET_F32 = false;
     static constexpr bool SHARED_STEP_BLOCK = false;
-    static constexpr int STEP_WAVES = 5;
+    static constexpr int STEP_BLOCK = 256, STEP_WAVES = 5;
     static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     using reward_t = float;
     static constexpr uint32_t CRIT_MASK = 0u;

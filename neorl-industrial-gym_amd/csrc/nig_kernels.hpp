@@ -293,9 +293,14 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
 // PowerGrid lanes finishing per step every wave would otherwise run the whole reset path for a
 // handful of active lanes).
 // ACT64: the action rows are float64 (nig_step64; CR / PG / RA only: the envs whose NumPy arithmetic then changes).
-template <class Env, bool PARITY, bool ACT64 = false>
-__global__ void __launch_bounds__(BLOCK, ACT64 ? 2 : Env::STEP_WAVES) step_kernel(const StepArgs p)
+// BLK: threads per block.  256, or Env::STEP_BLOCK for big fast-mode batches (PowerGrid: 512 -- the 12 KiB generator
+// table is then shared by eight waves and two blocks = 16 waves fit a CU next to their reset images, so a
+// 262 144-lane batch is resident in ONE round instead of 1.33: 30 -> 24 us per step; small batches keep 256 to
+// spread over all CUs).
+template <class Env, bool PARITY, bool ACT64 = false, int BLK = 256>
+__global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVES)) step_kernel(const StepArgs p)
 {
+    constexpr int BLOCK = BLK;             // shadows the file-wide constant inside this kernel
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     constexpr int NWAVE = BLOCK / 64;
@@ -1334,7 +1339,10 @@ static void launch_mlp(const MlpArgs &q, unsigned grid, hipStream_t st)
 template <class Env>
 static void launch_step(const StepArgs &a, bool parity, unsigned grid, hipStream_t st)
 {
+    constexpr int FB = Env::STEP_BLOCK;
     if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a);
+    else if (FB != BLOCK && a.B > 768u * BLOCK)       // more 256-thread blocks than are resident at once (3 per CU)
+        hipLaunchKernelGGL((step_kernel<Env, false, false, FB>), dim3((a.B + FB - 1) / FB), dim3(FB), 0, st, a);
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
