@@ -393,6 +393,9 @@ nig_handle *nig_mixed_segment(const nig_mixed *m, int32_t k);   /* borrowed hand
                                                                constraint mask, nig_step ... all per-handle calls */
 int nig_mixed_reset(nig_mixed *m, void *stream);            /* IndustrialEnv.reset for every lane, fast mode    */
 int nig_mixed_fill_actions(nig_mixed *m, uint32_t t, float *actions /* [A_max][ld] */, void *stream);
+/* IndustrialEnv.step for every lane (fast mode): actions float [A_max][ld] (rows >= A of a segment ignored),
+ * reward_out float [ld] / flags_out uint32 [ld] optional.  One step-kernel launch per segment on `stream`. */
+int nig_mixed_step(nig_mixed *m, const float *actions, float *reward_out, uint32_t *flags_out, void *stream);
 /* n_steps of IndustrialEnv.step for every lane of every segment in ONE launch; arguments as nig_rollout with
  * ld_act = ld: action_ring slot s at action_ring + s*slot_stride laid out [A_max][ld]; reward_out / flags_out
  * rows [ld] (both or neither), row of step k at base + k*out_stride (0 = overwrite). */

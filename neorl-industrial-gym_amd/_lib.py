@@ -32,7 +32,7 @@ SYMBOLS = [
     "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
     "nig_step64", "nig_step_host64", "nig_reduce_metrics",
     "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
-    "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed",
+    "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step",
 ]
 
 
@@ -138,6 +138,7 @@ def lib():
     L.nig_mixed_reset.argtypes = [vp, vp]
     L.nig_mixed_fill_actions.argtypes = [vp, u32, vp, vp]
     L.nig_mixed_rollout.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64, vp]
+    L.nig_mixed_step.argtypes = [vp, vp, vp, vp, vp]
     L.nig_rollout_mixed.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, i32, vp, i64, i64, i32, vp, vp, i64, vp]
     _lib = L
     return L

@@ -582,40 +582,35 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
     if (hidden != MLP_H) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: hidden must be 256 (agents/networks.py default)%s");
     const int S = SPECS[h->env].state_dim, A = SPECS[h->env].action_dim, H = MLP_H;
     if (S % 2 != 0 || A > 8) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: env shape not supported%s");
-    const int nrec = mlp_records(S);
-    float *host = (float *)calloc((size_t)nrec * 64, sizeof(float));
+    float *host = (float *)calloc((size_t)MLP_STREAM_FLOATS, sizeof(float));
     if (!host) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: out of host memory%s");
-    // Build the operand stream in exactly the order rollout_mlp_kernel consumes it.  Record = 64 floats;
-    // lane l = (i = l & 31, hf = l >> 5) holds W[k(hf)][32*tile + i].
-    int r = 0;
-    for (int m = 0; m < MLP_MT; ++m) {                      // layer 1, natural k order: k = 2*ks + hf
-        for (int ks = 0; ks < S / 2; ++ks, ++r)
-            for (int l = 0; l < 64; ++l) host[(size_t)r * 64 + l] = W1[(size_t)(2 * ks + (l >> 5)) * H + 32 * m + (l & 31)];
-        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b1[32 * m + l];
-        ++r;
+    // Build the operand stream in exactly the order rollout_mlp_kernel consumes it, chunk by chunk (a chunk = one
+    // fill of an LDS buffer, MLP_CHREC record slots, zero padded).  Record = 64 floats; lane l = (i = l & 31,
+    // hf = l >> 5) holds W[k(hf)][32*tile + i].
+    auto rec = [&](int chunk, int r) { return host + ((size_t)chunk * MLP_CHREC + r) * 64; };
+    for (int m = 0; m < MLP_MT; ++m) {                      // chunk 0: layer 1, natural k order: k = 2*ks + hf
+        const int R1 = S / 2 + 1;
+        for (int ks = 0; ks < S / 2; ++ks)
+            for (int l = 0; l < 64; ++l) rec(0, m * R1 + ks)[l] = W1[(size_t)(2 * ks + (l >> 5)) * H + 32 * m + (l & 31)];
+        for (int l = 0; l < 32; ++l) rec(0, m * R1 + S / 2)[l] = b1[32 * m + l];
     }
-    for (int m2 = 0; m2 < MLP_MT; ++m2) {
+    for (int m2 = 0; m2 < MLP_MT; ++m2) {                   // chunk 1 + m2
+        int r = 0;
         for (int kt = 0; kt < MLP_MT; ++kt)                   // layer 2: k follows the accumulator register order of h1
             for (int t = 0; t < 16; ++t, ++r)
                 for (int l = 0; l < 64; ++l)
-                    host[(size_t)r * 64 + l] = W2[(size_t)(32 * kt + mfma_row(t, l >> 5)) * H + 32 * m2 + (l & 31)];
-        for (int l = 0; l < 32; ++l) host[(size_t)r * 64 + l] = b2[32 * m2 + l];
+                    rec(1 + m2, r)[l] = W2[(size_t)(32 * kt + mfma_row(t, l >> 5)) * H + 32 * m2 + (l & 31)];
+        for (int l = 0; l < 32; ++l) rec(1 + m2, r)[l] = b2[32 * m2 + l];
         ++r;
         for (int t = 0; t < 16; ++t, ++r)                     // head: rows i >= A are zero
             for (int l = 0; l < 64; ++l)
-                if ((l & 31) < A) host[(size_t)r * 64 + l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+                if ((l & 31) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+        if (r != MLP_PER) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
     }
-    for (int l = 0; l < A; ++l) host[(size_t)r * 64 + l] = b3[l];
-    ++r;
-    if (r != nrec) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
+    for (int l = 0; l < A; ++l) rec(MLP_MT, MLP_PER)[l] = b3[l];     // the head's bias rides at the end of the last chunk
     hipError_t e = hipSuccess;
-    // the kernel prefetches up to 29 records past the end (values unused): keep them inside the allocation
-    if (!h->mlp_stream) {
-        const size_t bytes = (size_t)(mlp_records(32) + 32) * 64 * sizeof(float);
-        e = hipMalloc((void **)&h->mlp_stream, bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(h->mlp_stream, 0, bytes, (hipStream_t)stream);
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)nrec * 64 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (!h->mlp_stream) e = hipMalloc((void **)&h->mlp_stream, (size_t)MLP_STREAM_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)MLP_STREAM_FLOATS * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free(host);
     if (e != hipSuccess) return fail(NIG_ERR_HIP, "nig_set_mlp_policy: %s", hipGetErrorString(e));
@@ -982,6 +977,18 @@ int nig_mixed_fill_actions(nig_mixed *m, uint32_t t, float *actions, void *strea
     if (!m || !actions) return fail(NIG_ERR_INVALID, "nig_mixed_fill_actions: NULL argument%s");
     for (int k = 0; k < m->n; ++k) {
         const int rc = nig_fill_actions(m->seg[k], t, actions + m->off[k], m->ld, stream);
+        if (rc != NIG_OK) return rc;
+    }
+    return NIG_OK;
+}
+
+int nig_mixed_step(nig_mixed *m, const float *actions, float *reward_out, uint32_t *flags_out, void *stream)
+{
+    if (!m || !actions) return fail(NIG_ERR_INVALID, "nig_mixed_step: NULL argument%s");
+    for (int k = 0; k < m->n; ++k) {              // one step kernel per segment (each its own env type), same stream
+        const int64_t o = m->off[k];
+        const int rc = nig_step(m->seg[k], actions + o, m->ld, nullptr, nullptr, 0, reward_out ? reward_out + o : nullptr, nullptr,
+                                flags_out ? flags_out + o : nullptr, nullptr, 0, stream);
         if (rc != NIG_OK) return rc;
     }
     return NIG_OK;

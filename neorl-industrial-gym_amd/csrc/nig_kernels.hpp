@@ -1083,7 +1083,17 @@ struct MlpArgs {
 };
 
 constexpr int MLP_H = 256, MLP_MT = MLP_H / 32;
-__host__ __device__ constexpr int mlp_records(int S) { return MLP_MT * (S / 2 + 1) + MLP_MT * (MLP_MT * 16 + 1 + 16) + 1; }
+// The operand stream is cut into 1 + MLP_MT CHUNKS of MLP_CHREC records (256 bytes each, padded): chunk 0 = layer 1
+// (MLP_MT tiles of S/2 weight records + 1 bias record), chunk 1 + m2 = hidden tile m2 of layer 2 with its slice of
+// the head (128 + 1 + 16 records; the last chunk also carries the head's bias record).  A chunk is what one fill of
+// an LDS buffer holds: MLP_PIECES wave-instructions of 1 KiB (64 lanes x 16 bytes, LDS-DMA).
+constexpr int MLP_PER = MLP_MT * 16 + 1 + 16;                 // 145 records per hidden tile
+constexpr int MLP_PIECES = (MLP_PER + 1 + 3) / 4;             // 37 KiB pieces per chunk
+constexpr int MLP_CHREC = MLP_PIECES * 4;                     // 148 records per chunk slot
+constexpr int MLP_CHUNKS = 1 + MLP_MT;
+constexpr int MLP_STREAM_FLOATS = MLP_CHUNKS * MLP_CHREC * 64;
+typedef __attribute__((address_space(3))) void nig_lds_void;
+typedef __attribute__((address_space(1))) const void nig_glb_void;
 
 template <class Env>
 __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
@@ -1091,9 +1101,16 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     static_assert(S % 2 == 0 && A <= 8, "MFMA actor needs an even state dim and at most 8 actions");
+    // Weight records are shared by the four waves of the block through LDS: round 1 let every wave stream all
+    // ~1 200 records of a step from L2 on its own (the same 256-byte lines requested by every wave of the chip at
+    // about the same time: 96 TFLOP/s of 155).  Now the block fills a double-buffered LDS image chunk by chunk with
+    // LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no registers), nine fills per step, each wave a
+    // quarter of the pieces, the fill of chunk c+1 in flight while chunk c is consumed; an MFMA's A operand is one
+    // ds_read_b32.  L2 traffic per block and step: 311 KB instead of 4 x 311 KB.
+    __shared__ __attribute__((aligned(16))) float s_w[2][MLP_CHREC * 64];
     NIG_STAGE_PROBIT(s_probit);
     const StepArgs &p = q.s;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, half = lane >> 5, e = lane & 31u, wave = tid >> 6;
     const uint32_t lane0 = blockIdx.x * (BLOCK / 2) + (tid >> 6) * 32u;     // first env of this wave
     const uint32_t li = lane0 + e;
     const bool in_range = li < p.B;
@@ -1111,56 +1128,57 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     double ret = (tally && in_range) ? p.ep_ret[li] : 0.0;
     LaneTally lt;
     lt.clear();
+    // fill LDS buffer `buf` with chunk `c` of the operand stream: this wave's quarter of the KiB pieces
+    auto fill = [&](int c, int buf, int pieces) __attribute__((always_inline)) {
+        const float *src = q.wstream + (size_t)c * (MLP_CHREC * 64) + lane * 4u;
+        for (int pc = (int)wave; pc < pieces; pc += BLOCK / 64)
+            __builtin_amdgcn_global_load_lds((nig_glb_void *)(src + pc * 256), (nig_lds_void *)(&s_w[buf][pc * 256]), 16, 0, 0);
+    };
+    constexpr int R1 = S / 2 + 1;                            // records per layer-1 tile
+    constexpr int PIECES0 = (MLP_MT * R1 + 3) / 4;           // pieces of chunk 0
+    static_assert(MLP_MT * R1 <= MLP_CHREC, "layer 1 must fit one chunk");
+    fill(0, 0, PIECES0);
+    int gbuf = 0;                                            // buffer that holds (or receives) the chunk consumed next
     for (int it = 0; it < q.n_steps; ++it) {
         // ---------------- actor: 3 layers of f32 MFMA, whole wave (EXEC all ones) ----------------
-        // A operands come from the pre-ordered weight stream (block-uniform base + lane), one
-        // 256-byte record per MFMA.  An MFMA issues every 64 cycles and an L2 hit takes ~500-900, so
-        // records are fetched RING = 29 MFMAs ahead through a register ring (145 records per
-        // hidden-tile iteration = 5 x 29: ring slots are compile-time constants).
-        const float *w = q.wstream;                          // uniform; lane offset added per access
+        // chunk boundary: every wave's share of the fill has landed (the compiler drains vmcnt before the barrier)
+        // and every wave is done with the buffer the next fill overwrites
+        __syncthreads();
+        fill(1, gbuf ^ 1, MLP_PIECES);
         f32x16 h1[MLP_MT];
         {
-            constexpr int R1 = S / 2 + 1;                    // records per layer-1 tile
-            float cur[R1], nxt[R1];
-#pragma unroll
-            for (int j = 0; j < R1; ++j) cur[j] = w[j * 64 + lane];
+            const float *wb = &s_w[gbuf][lane];
 #pragma unroll
             for (int m = 0; m < MLP_MT; ++m) {
-                if (m + 1 < MLP_MT) {
-#pragma unroll
-                    for (int j = 0; j < R1; ++j) nxt[j] = w[(R1 + j) * 64 + lane];
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < S / 2; ++ks) {
                     const float b = half ? s[2 * ks + 1] : s[2 * ks];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ks], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[(m * R1 + ks) * 64], b, acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[R1 - 1], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b1
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[(m * R1 + R1 - 1) * 64], half ? 0.0f : 1.0f, acc, 0, 0, 0);   // + b1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);                                   // ReLU
                 h1[m] = acc;
-                w += R1 * 64;
-#pragma unroll
-                for (int j = 0; j < R1; ++j) cur[j] = nxt[j];
             }
         }
+        gbuf ^= 1;
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        constexpr int RING = 29, PER = MLP_MT * 16 + 1 + 16;     // 145 records per m2 iteration
-        static_assert(PER % RING == 0, "ring slots must be static across iterations");
-        float ring[RING];
-#pragma unroll
-        for (int j = 0; j < RING; ++j) ring[j] = w[j * 64 + lane];
-        for (int m2 = 0; m2 < MLP_MT; ++m2) {          // a real loop: the body is 145 MFMAs of straight-line code
+        constexpr int RING = 8;                             // LDS reads in flight ahead of their MFMA (~64 cycles apart)
+        for (int m2 = 0; m2 < MLP_MT; ++m2) {               // a real loop: the body is 145 MFMAs of straight-line code
+            __syncthreads();                                // chunk 1 + m2 is in s_w[gbuf]; s_w[gbuf ^ 1] is free
+            if (m2 + 1 < MLP_MT) fill(2 + m2, gbuf ^ 1, MLP_PIECES);
+            else if (it + 1 < q.n_steps) fill(0, gbuf ^ 1, PIECES0);   // layer 1 of the NEXT step (the weights do not change)
+            const float *wb = &s_w[gbuf][lane];
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const float *wn = w + RING * 64;           // record i + RING (the stream is padded past its end)
+            float ring[RING];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
+            for (int j = 0; j < RING; ++j) ring[j] = wb[j * 64];
+#pragma unroll
+            for (int i = 0; i < MLP_PER; ++i) {
                 const float aop = ring[i % RING];
-                ring[i % RING] = wn[i * 64 + lane];
-                // pin the source order: hipcc's scheduler otherwise sinks every prefetch to just before
-                // its use (one load in flight, MFMA pipe idle ~75 % of the time)
+                if (i + RING < MLP_PER + 1) ring[i % RING] = wb[(i + RING) * 64];       // (+1: the head's bias record of the last chunk)
+                // pin the source order: hipcc's scheduler otherwise sinks every read to just before its use
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < MLP_MT * 16) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, h1[i / 16][i % 16], acc, 0, 0, 0);
@@ -1171,9 +1189,10 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            w += PER * 64;
+            if (m2 + 1 == MLP_MT)                            // record 145 of the last chunk: + b3
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out, 0, 0, 0);
+            gbuf ^= 1;
         }
-        out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[0], half ? 0.0f : 1.0f, out, 0, 0, 0);             // + b3
         // action j sits in register j&3 of lane half j>>2: hand every lane all A of them
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

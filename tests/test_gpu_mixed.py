@@ -204,6 +204,18 @@ def test_mixed_abi_argument_checks(ni):
     assert L.nig_mixed_rollout(h, 3, C.c_void_p(ring.data_ptr()), 100, 1, None, None, 0, None) == 1                             # slot too small
     lib.check(L.nig_mixed_reset(h, None))
     lib.check(L.nig_mixed_rollout(h, 3, C.c_void_p(ring.data_ptr()), 8 * 512, 1, None, None, 0, None))
+    # nig_mixed_step == the per-segment step kernels on the same columns
+    fl = torch.zeros(512, dtype=torch.int32, device="cuda:0")
+    act = torch.rand(8, 512, device="cuda:0") * 2 - 1
+    solo = [ni.make_batched(n, 10, seed=1, env_index0=o) for n, o in (("ChemicalReactor-v0", 0), ("PowerGrid-v0", 256))]
+    for e, o in zip(solo, (0, 256)):
+        e.reset()
+        e.rollout(3, ring[:, :e.action_dim, o:o + 10])
+    lib.check(L.nig_mixed_step(h, C.c_void_p(act.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(fl.data_ptr()), None))
+    for e, o in zip(solo, (0, 256)):
+        _, r, _, _, info = e.step(act[:e.action_dim, o:o + 10], layout="soa")
+        assert torch.equal(r, rew[o:o + 10]) and torch.equal(info.flags, fl[o:o + 10])
+        e.close()
     torch.cuda.synchronize()
     assert L.nig_mixed_segment(h, 2) is None and L.nig_mixed_segment(h, 1)
     L.nig_mixed_destroy(h)
