@@ -928,6 +928,11 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     // the loads nor uses the scalar cache) -- ~20 serialised L2 round trips per step, 60 % of the step.
     __shared__ nig_policy s_pol;
     __shared__ v4f s_tr[BLOCK / 64][16 * S];       // per-wave transpose of the row-major observation rows
+    // envs with a cooperative reset (PowerGrid: ~11 finishing lanes per wave and step) renew them wave by wave as
+    // the open-loop rollout does (coop_reset); the in-place form ran the whole reset path in every wave every step
+    constexpr bool COOP = Env::COOP_RESET;
+    __shared__ float s_img[COOP ? (BLOCK / 64) * Env::RESET_ROWS * 64 : 1];
+    __shared__ unsigned char s_wlist[COOP ? BLOCK : 1];
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s_pol);
@@ -938,36 +943,44 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const uint32_t base = blockIdx.x * BLOCK;
-    if (base + tid >= p.B) return;
+    const bool in_range = base + tid < p.B;
+    if constexpr (COOP) {
+        if (base + (tid & ~63u) >= p.B) return;    // a partial wave keeps all 64 lanes: they are the reset's workers
+    } else {
+        if (!in_range) return;
+    }
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
     const uint64_t gi = p.env0 + (uint64_t)(base + tid);
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
     const bool tally = p.tally != nullptr;
 
-    uint32_t ctr = (p.ctr + base)[tid];
+    uint32_t ctr = in_range ? (p.ctr + base)[tid] : (uint32_t)NIG_CTR_DONE;     // out-of-range lanes idle as frozen
     float s[S], a[A], n[S], integ[A], eprev[A];
     typename Env::fast_noise_t nz[KSN];
 #pragma unroll
-    for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[tid];
+    for (int k = 0; k < S; ++k) s[k] = in_range ? (p.state + base + k * p.ld_state)[tid] : 0.0f;
     // PID memory lives in the handle (baseline_agents.py:55-80: integral and previous error are the agent's,
     // never reset): loaded here, stored at the end, so launches chain exactly
-    const bool pid_mem = q.pid != nullptr && pol->kind == NIG_POLICY_PID;
+    const bool pid_mem = q.pid != nullptr && pol->kind == NIG_POLICY_PID && in_range;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
         integ[j] = pid_mem ? (q.pid + base + (size_t)j * p.ld)[tid] : 0.0f;
         eprev[j] = pid_mem ? (q.pid + base + (size_t)(A + j) * p.ld)[tid] : 0.0f;
     }
-    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    double ret = (tally && in_range) ? (p.ep_ret + base)[tid] : 0.0;
     LaneTally lt;
     lt.clear();
 
     for (int it = 0; it < q.n_steps; ++it) {
         const uint32_t orow = (uint32_t)it * q.out_stride;
-        if (ctr & NIG_CTR_DONE) {                  // frozen lane: base.py:159-160
-            if (p.flags) (p.flags + base + orow)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
-            if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
-            continue;
-        }
+        bool need_reset = false;
+        const bool live = !(ctr & NIG_CTR_DONE);
+        if (!live) {                               // frozen lane: base.py:159-160
+            if (in_range) {
+                if (p.flags) (p.flags + base + orow)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
+                if (p.reward) (p.reward + base + orow)[tid] = 0.0f;
+            }
+        } else {
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         policy_action<Env>(pol, s, key, integ, eprev, a);
         if (q.obs_out) {
@@ -1027,17 +1040,32 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
             lt.life += (long long)viol_ep;
             if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
             if (autoreset) {
-                double rn[KR > 0 ? KR : 1];
-                Env::draw_init(key, rn);
-                Env::init(rn, n);
+                if constexpr (COOP) {
+                    need_reset = true;
+                } else {
+                    double rn[KR > 0 ? KR : 1];
+                    Env::draw_init(key, rn);
+                    Env::init(rn, n);
+                }
                 ctr = 0u;
             } else {
                 ctr |= NIG_CTR_DONE;
             }
         }
+        }   // live
+        if constexpr (COOP) {                      // every lane of the wave arrives here, whatever its own state
+            const unsigned long long m = __ballot(need_reset);
+            if (m != 0ull)
+                coop_reset<Env>(m, need_reset, tid & 63u, s_img + (tid >> 6) * (Env::RESET_ROWS * 64), s_wlist + (tid >> 6) * 64,
+                                p.env0 + (uint64_t)(base + (tid & ~63u)), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi,
+                                s_probit, n);
+        }
+        if (live) {
 #pragma unroll
-        for (int k = 0; k < S; ++k) s[k] = n[k];
+            for (int k = 0; k < S; ++k) s[k] = n[k];
+        }
     }
+    if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
     (p.ctr + base)[tid] = ctr;
