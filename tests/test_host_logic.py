@@ -208,3 +208,46 @@ def test_constant_division_is_correctly_rounded(tmp_path):
     out = subprocess.run([str(exe)] + consts, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert out.stdout.count("mismatches=0") == len(consts), out.stdout
+
+
+def test_stale_library_is_never_rebuilt_under_a_profiler(monkeypatch):
+    """ADVICE (round 1): importing the package inside a rocprofv3-preloaded process rebuilt a stale libnig.so
+    there (hipcc -> sh -c -> clang++ from a GPU-initialised process).  _build.ensure() must refuse instead."""
+    from neorl_industrial_gym_amd import _build
+    assert not _build.stale(), "the test needs a current library (run __graft_entry__.build())"
+    assert _build.ensure() == _build.LIB                      # current: nothing to do, whatever the environment
+    monkeypatch.setattr(_build, "stale", lambda: True)
+    called = []
+    monkeypatch.setattr(_build, "build", lambda **kw: called.append(kw) or _build.LIB)
+    monkeypatch.setenv("NIG_NO_AUTOBUILD", "1")
+    with pytest.raises(ImportError, match="auto-build is disabled"):
+        _build.ensure()
+    monkeypatch.delenv("NIG_NO_AUTOBUILD")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    with pytest.raises(ImportError, match="auto-build is disabled"):
+        _build.ensure()
+    assert not called
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert _build.ensure() == _build.LIB and len(called) == 1  # only local rank 0 compiles
+
+
+def test_build_hash_covers_every_source_of_the_library():
+    """Staleness is a content hash over csrc/*.hip, *.hpp, *.inc and include/nig.h (round 1 missed the .inc files)."""
+    from neorl_industrial_gym_amd import _build
+    names = {os.path.basename(p) for p in _build.sources() + _build.headers()}
+    for f in ("nig_api.hip", "nig_mixed.hip", "env_pg.hip", "nig_kernels.hpp", "nig_envs.hpp", "nig_detmath.hpp",
+              "nig_probit_table.inc", "nig_spec_plants.inc", "nig.h"):
+        assert f in names, f
+
+
+def test_bench_traffic_lookup_is_per_env_step_and_keyed_by_plan_length():
+    sys.path.insert(0, ROOT)
+    import bench
+    per_step, src = bench.measured_traffic("cr", 65536, "rollout", "full", 250)
+    assert per_step is not None and 60.0 < per_step < 80.0 and "pmc" in src          # ~69 B vs 68 algorithmic
+    assert bench.measured_traffic("cr", 65536, "rollout", "full", 20) == (None, None)    # another launch length: no figure
+    assert bench.measured_traffic("cr", 12345, "rollout", "full", 250) == (None, None)
+    pg, _ = bench.measured_traffic("pg", 262144, "rollout", "full", 250)
+    assert pg is not None and 160.0 < pg < 190.0
+    assert bench.alg_bytes_rollout(12, 3, "full") == 68 and bench.alg_bytes_per_step(32, 8) == 304
