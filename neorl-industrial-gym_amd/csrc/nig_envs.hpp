@@ -47,6 +47,7 @@ struct ChemicalReactor {
     static constexpr bool CUSTOM_STEP = false, RET_F32 = true;   // episode_return stays np.float32 (utils.py:99 under NEP 50)
     static constexpr int STEP_BLOCK = 256, STEP_WAVES = 6;          // waves per SIMD the step kernel is compiled for (no spills at this cap: 80 VGPRs)
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels (four action register sets in flight)
+    static constexpr bool SPLIT_ROLLOUT = true;   // small batches: integrator + helper wave per 64 lanes (nig_split.hpp)
     using reward_t = float;   // reward stays np.float32 (0.0 + f32 under NEP 50), :240-269
     __device__ static constexpr float act_low(int) { return -1.0f; }      // base.py:66-71
     __device__ static constexpr float act_high(int) { return 1.0f; }

@@ -824,6 +824,10 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     rollout_body<Env, OUT, PAIRED, FULL>(q, (blockIdx.x + q.block0) * BLOCK, smem);
 }
 
+}  // namespace nig
+#include "nig_split.hpp"
+namespace nig {
+
 // Mixed-batch launch (nig_mixed.hip): per-segment rollout arguments + the block -> segment table, in launch order.
 constexpr int MIXED_MAX_SEG = NIG_MIXED_MAX_SEGMENTS;
 struct MixedArgs {
@@ -1413,12 +1417,33 @@ static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned g
     }
 }
 
+// Largest batch (in 256-lane blocks) the split form is used for; NIG_SPLIT_BLOCKS=0 switches it off (A/B runs, tests).
+static unsigned split_max_blocks()
+{
+    static const unsigned v = [] {
+        const char *e = getenv("NIG_SPLIT_BLOCKS");
+        return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
+    }();
+    return v;
+}
+
 // the batch's whole 256-lane blocks in one launch without lane predication, a ragged last block in its own
 template <class Env, bool PAIRED>
 static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*grid*/, hipStream_t st)
 {
     const unsigned n_full = q.s.B / BLOCK;
     RolloutArgs r = q;
+    if constexpr (PAIRED && split_rollout<Env>::value) {
+        // up to one 256-lane block per CU the batch leaves a single wave on every SIMD: integrator + helper wave
+        // per 64 lanes (nig_split.hpp).  Larger batches fill the SIMDs with lanes and keep the one-wave form.
+        const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+        if (plain && n_full > 0 && n_full <= split_max_blocks()) {
+            r.block0 = 0;
+            launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
+            if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
+            return;
+        }
+    }
     if (n_full > 0) { r.block0 = 0; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full, st); }
     if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
 }
