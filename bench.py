@@ -94,11 +94,14 @@ class Workload:
         env.reset()
         self.rew = self.fl = self.traj = None
         if mode == "rollout" and outputs != "none":
-            self.rew = torch.empty(P, env.ld, dtype=torch.float32, device=device)
-            self.fl = torch.empty(P, env.ld, dtype=torch.int32, device=device)
+            # NIG_DIAG_OVERWRITE=1 (diagnostic, never a headline): every step writes the SAME rows (row stride 0), so the
+            # stores are issued but stay in cache -- separates "bound by issuing the stores" from "bound by draining them"
+            rows = 1 if os.environ.get("NIG_DIAG_OVERWRITE") else P
+            self.rew = torch.empty(rows, env.ld, dtype=torch.float32, device=device).expand(P, env.ld)
+            self.fl = torch.empty(rows, env.ld, dtype=torch.int32, device=device).expand(P, env.ld)
             if outputs == "full":
-                self.traj = (torch.empty(P, B, self.S, dtype=torch.float32, device=device) if traj_layout == "aos"   # row-major [T,B,S]
-                             else torch.empty(P, self.S, env.ld, dtype=torch.float32, device=device))
+                self.traj = (torch.empty(rows, B, self.S, dtype=torch.float32, device=device).expand(P, B, self.S) if traj_layout == "aos"   # row-major [T,B,S]
+                             else torch.empty(rows, self.S, env.ld, dtype=torch.float32, device=device).expand(P, self.S, env.ld))
         self.plan = env.make_plan(P, self.ring, env.reward, env.flags) if mode == "graph" else None
 
     def launch(self):

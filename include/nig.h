@@ -128,6 +128,17 @@ typedef struct nig_handle nig_handle;
 const char *nig_version(void);
 const char *nig_last_error(void);
 
+/* Process-wide tuning knobs.  Results never depend on them: every kernel form a knob selects between is
+ * bit-identical (tests/test_gpu_split.py).  No counterpart upstream.
+ *   NIG_TUNE_SPLIT_BLOCKS   largest batch, in 256-lane blocks, that nig_rollout runs in the three-wave form
+ *                           (csrc/nig_split.hpp: producer / integrator / recorder wave per 64 ChemicalReactor
+ *                           lanes); default 256 = one block per CU, 0 = never.  The environment variable
+ *                           NIG_SPLIT_BLOCKS sets the initial value.
+ * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
+enum { NIG_TUNE_SPLIT_BLOCKS = 0 };
+int nig_tune(int32_t key, int64_t value);
+int64_t nig_tune_get(int32_t key);
+
 /* utils.make registry lookup (utils.py:26-35): name -> id, or -1 */
 int nig_env_id(const char *name);
 const char *nig_env_name(int env);
@@ -258,7 +269,9 @@ int nig_plan_destroy(nig_plan *p);
  *                a lane that finishes) at obs_out + k*obs_step_stride, laid out [S][ld_obs], or
  *                -- with ld_obs == 0 -- row-major [B][S] (the D4RL observations[N,S] layout; obs_out
  *                16-byte aligned and obs_step_stride a multiple of 4 floats, i.e. B*S % 4 == 0 for a
- *                dense trajectory: each wave's 64 rows leave as whole-line 16-byte streaming stores)
+ *                dense trajectory: each wave's 64 rows leave as whole-line 16-byte streaming stores).
+ *                obs_step_stride == 0: every step overwrites the same block (as out_stride == 0 does for the
+ *                reward / flag rows) -- the caller keeps the observations the last step returned
  * Stands in for the step loops of the reference's harnesses: benchmark_environment_steps
  * (performance_benchmark.py:106-133) and the get_dataset episode loops
  * (chemical_reactor.py:364-405, power_grid.py:209-237, robot_assembly.py:259-296).

@@ -22,11 +22,21 @@ from .policies import (DevicePolicy, MLPPolicy, behaviour_policy, constant_agent
                        pid_agent, random_agent)
 from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
 
+def tune(split_blocks=None):
+    """Process-wide kernel-selection knobs of libnig (include/nig.h nig_tune); results never depend on them.
+    split_blocks: largest batch, in 256-lane blocks, that rollout() runs in the three-wave form (0 = never).
+    Returns the current settings."""
+    L = _lib.lib()
+    if split_blocks is not None:
+        _lib.check(L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, int(split_blocks)))
+    return {"split_blocks": int(L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS))}
+
+
 __version__ = "0.1.0"
 __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
     "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "AdvancedChemicalReactorEnv", "AdvancedPowerGridEnv",
     "HVACControlEnv", "WaterTreatmentEnv", "SteelAnnealingEnv", "SupplyChainEnv", "BatchedIndustrialEnv", "MixedBatchedEnv", "StepInfo",
-    "make", "make_batched", "evaluate_with_safety", "DevicePolicy", "MLPPolicy", "behaviour_policy", "constant_agent",
+    "make", "make_batched", "evaluate_with_safety", "tune", "DevicePolicy", "MLPPolicy", "behaviour_policy", "constant_agent",
     "mpc_agent", "pid_agent", "random_agent",
 ]

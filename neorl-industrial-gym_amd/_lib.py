@@ -25,6 +25,8 @@ MAX_EPISODE_STEPS = 21845
 (T_EPISODES, T_RET_SUM, T_RET_SQ, T_RET_MIN, T_RET_MAX, T_LEN_SUM, T_LEN_SQ, T_VIOL, T_CRIT,
  T_SHUTDOWN, T_SUCCESS, T_SATISFIED, T_CONSTRAINTS, T_ROWS) = range(14)
 
+TUNE_SPLIT_BLOCKS = 0
+
 SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
@@ -33,6 +35,7 @@ SYMBOLS = [
     "nig_step64", "nig_step_host64", "nig_reduce_metrics",
     "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
     "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step",
+    "nig_tune", "nig_tune_get",
 ]
 
 
@@ -94,6 +97,9 @@ def lib():
     vp, i64, u32, u64, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_int32
     L.nig_version.restype = C.c_char_p
     L.nig_last_error.restype = C.c_char_p
+    L.nig_tune.argtypes = [C.c_int32, C.c_int64]
+    L.nig_tune_get.argtypes = [C.c_int32]
+    L.nig_tune_get.restype = C.c_int64
     L.nig_env_id.argtypes = [C.c_char_p]
     L.nig_env_name.restype = C.c_char_p
     L.nig_env_name.argtypes = [C.c_int]

@@ -236,10 +236,25 @@ static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, h
     launch_of(h->env)->step(a, parity, grid_for(h->B), st);
 }
 
+namespace nig {
+unsigned g_split_blocks = [] {
+    const char *e = getenv("NIG_SPLIT_BLOCKS");
+    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;        // one 256-lane block per CU
+}();
+}
+
 extern "C" {
 
 const char *nig_version(void) { return "nig 0.1.0 (gfx950)"; }
 const char *nig_last_error(void) { return g_err; }
+
+int nig_tune(int32_t key, int64_t value)
+{
+    if (key != NIG_TUNE_SPLIT_BLOCKS || value < 0 || value > 0x7fffffffLL) return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
+    nig::g_split_blocks = (unsigned)value;
+    return NIG_OK;
+}
+int64_t nig_tune_get(int32_t key) { return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::g_split_blocks : -1; }
 
 int nig_env_id(const char *name)
 {
@@ -492,10 +507,11 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
         return fail(NIG_ERR_INVALID, "nig_rollout: out_stride outside {0} U [batch, 2^26]%s");
     if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: n_steps*out_stride >= 2^32%s");
     const bool obs_aos = obs_out && ld_obs == 0;
-    if (obs_out && !obs_aos && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH || obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs))
+    if (obs_out && !obs_aos && (ld_obs < h->B || ld_obs > NIG_MAX_PITCH ||
+                                (obs_step_stride != 0 && obs_step_stride < (int64_t)SPECS[h->env].state_dim * ld_obs)))
         return fail(NIG_ERR_INVALID, "nig_rollout: bad observation trajectory pitch%s");
-    if (obs_aos && (obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
-        return fail(NIG_ERR_INVALID, "nig_rollout: row-major trajectory needs 16-byte alignment and obs_step_stride >= S*batch (multiple of 4)%s");
+    if (obs_aos && ((obs_step_stride != 0 && obs_step_stride < (int64_t)SPECS[h->env].state_dim * h->B) || (obs_step_stride & 3) || ((uintptr_t)obs_out & 15)))
+        return fail(NIG_ERR_INVALID, "nig_rollout: row-major trajectory needs 16-byte alignment and obs_step_stride 0 or >= S*batch (multiple of 4)%s");
     if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: launch counter would wrap%s");
     RolloutArgs q;
     memset(&q, 0, sizeof q);

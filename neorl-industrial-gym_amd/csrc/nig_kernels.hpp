@@ -1417,15 +1417,8 @@ static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned g
     }
 }
 
-// Largest batch (in 256-lane blocks) the split form is used for; NIG_SPLIT_BLOCKS=0 switches it off (A/B runs, tests).
-static unsigned split_max_blocks()
-{
-    static const unsigned v = [] {
-        const char *e = getenv("NIG_SPLIT_BLOCKS");
-        return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
-    }();
-    return v;
-}
+// Largest batch (in 256-lane blocks) the three-wave form is used for (nig_tune(NIG_TUNE_SPLIT_BLOCKS); nig_api.hip).
+extern unsigned g_split_blocks;
 
 // the batch's whole 256-lane blocks in one launch without lane predication, a ragged last block in its own
 template <class Env, bool PAIRED>
@@ -1437,7 +1430,7 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
         // up to one 256-lane block per CU the batch leaves a single wave on every SIMD: integrator + helper wave
         // per 64 lanes (nig_split.hpp).  Larger batches fill the SIMDs with lanes and keep the one-wave form.
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        if (plain && n_full > 0 && n_full <= split_max_blocks()) {
+        if (plain && n_full > 0 && n_full <= g_split_blocks) {
             r.block0 = 0;
             launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
             if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }

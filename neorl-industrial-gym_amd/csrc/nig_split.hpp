@@ -1,29 +1,32 @@
 // nig_split.hpp -- the fused rollout for batches that leave ONE wave per SIMD (included by nig_kernels.hpp).
 //
 // At BASELINE.json's headline size (65 536 lanes = 1024 waves on 1024 SIMDs) the rollout kernel is bound by what a
-// single wave can issue: a lone wave reaches about half of its SIMD's VALU rate (profiles/ubench/valu_rate.hip),
-// and the lane-count probe (profiles/r02/scale_probe.txt) shows the same thing on the kernel itself -- twice the
-// lanes cost 1.25x the time.  More lanes per SIMD are not available at that batch size, so this kernel puts a
-// SECOND wave on every SIMD that works on the SAME 64 environments:
+// single wave can issue: a lone wave gets one VALU instruction issued every 5-7 cycles where the SIMD could take
+// one every ~2.5 (profiles/ubench/valu_rate.hip), and the lane-count probe (profiles/r02/scale_probe.txt) shows
+// the same thing on the kernel itself -- twice the lanes cost 1.25x the time.  More lanes per SIMD are not
+// available at that batch size, so this kernel puts THREE waves on every SIMD that work on the SAME 64
+// environments, each with a third of IndustrialEnv.step:
 //
-//   integrator wave (I): owns the state.  Per step: constraint check on the pre-state, dynamics, done /
-//       truncation, in-kernel reset.  Touches no global memory inside the loop.
-//   helper wave (H):     everything around it.  Runs D steps AHEAD producing what the integrator consumes
-//       (Philox + normal transform of the process noise, action load + clip) and one step BEHIND consuming what it
-//       leaves (reward, penalties, flag word, episode tally, the transposed trajectory rows and all the stores).
+//   producer   (P): what a step consumes.  Philox + normal transform of the process noise, action load + clip.
+//                   Runs ahead of the integrator by up to the ring length.  Loads only, no stores.
+//   integrator (I): owns the state.  Constraint check on the pre-state, dynamics, done / truncation, in-kernel
+//                   reset.  Touches no global memory inside the loop.  The critical path of the three.
+//   recorder   (C): what a step leaves behind.  Reward, penalties, flag word, episode tally, the transposed
+//                   trajectory rows and ALL the stores.  Stores only, no loads: it never waits on vmcnt.
 //
-// The two exchange through two rings of K slots in LDS, each guarded by one monotonically increasing counter
-// (slots produced so far).  H -> I slot: the KS noise values and A clipped actions of one step, [row][lane].
-// I -> H slot: the S post-dynamics state values row-major [lane][S] (this IS the transposing image of the
-// row-major trajectory) plus the violation bits of the pre-state.  DS operations of one wave execute in order, so
-// "write data, then write counter" / "read counter, then read data" needs no wait in between; the wavefront-scope
-// fences only pin the compiler's order.  No block barrier inside the loop, no flow control beyond the two
-// counters: I cannot run further ahead of H's reads than D+1 slots because it needs H's output for every step
-// (K >= D + 2), and H produces slot i+D only after it consumed slot i-1.
+// They exchange through two rings of K slots in LDS, each guarded by a monotonically increasing counter (slots
+// produced so far), plus the recorder's count of slots it is done with.  P -> I slot: the KS noise values and A
+// clipped actions of one step, [row][lane].  I -> C slot: the S post-dynamics state values row-major [lane][S]
+// (this IS the transposing image of the row-major trajectory) plus the violation bits of the pre-state; C also
+// reads the clipped action back from the P -> I slot.  DS operations of one wave execute in order, so "write data,
+// then write counter" / "read counter, then read data" needs no wait in between; the wavefront-scope fences only
+// pin the compiler's order.  No block barrier inside the loop.  Flow control: P writes slot j only after C is
+// done with slot j - K; I needs P's slot j before it writes its own slot j, so it cannot overrun C either.
 //
 // The arithmetic is the other kernels': same clip, violated, dynamics, post_core, pack_flags, tally and reset
 // calls on the same values with the same generator keys -- the results are bit-identical to rollout_kernel's
-// (tests/test_gpu_parity.py, tests/test_spec_envs.py: the fused-rollout tests run both forms).
+// (tests/test_gpu_parity.py, tests/test_spec_envs.py: the fused-rollout tests run this form wherever it applies,
+// tests/test_gpu_split.py pins it against the one-wave form).
 #pragma once
 
 namespace nig {
@@ -33,19 +36,17 @@ template <class E> struct split_rollout<E, std::void_t<decltype(E::SPLIT_ROLLOUT
 
 template <class Env, int NP>
 struct SplitLds {
-    static constexpr int D = 4;                  // steps the helper produces ahead (== depth of its action register ring)
-    static constexpr int K = 6;                  // ring slots (>= D + 2)
+    static constexpr int K = 6;                  // ring slots
     static constexpr int HI_ROWS = Env::KS + Env::A;
     static constexpr int HI_SLOT = HI_ROWS * 64;             // floats
     static constexpr int IH_SLOT = (Env::S + 1) * 64;        // floats: [64][S] state rows, then [64] violation words
     static constexpr int OFF_PROBIT = 0;
     static constexpr int OFF_IMG = 768 * 16;                                   // float [NP][RESET_ROWS][64]
     static constexpr int OFF_WLIST = OFF_IMG + NP * Env::RESET_ROWS * 64 * 4;  // uchar [NP][64]
-    static constexpr int OFF_SYNC = OFF_WLIST + NP * 64;                       // uint32 [NP][4]: {produced H->I, produced I->H}
+    static constexpr int OFF_SYNC = OFF_WLIST + NP * 64;                       // uint32 [NP][4]: {P produced, I produced, C done}
     static constexpr int OFF_HI = OFF_SYNC + NP * 16;
     static constexpr int OFF_IH = OFF_HI + NP * K * HI_SLOT * 4;
     static constexpr int BYTES = OFF_IH + NP * K * IH_SLOT * 4;
-    static_assert(K >= D + 2, "ring too short for the run-ahead");
     static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
 
@@ -53,13 +54,17 @@ struct SplitLds {
 // is compiled to a system-coherent FLAT operation with a vmcnt(0) wait behind it.
 using lds_u32_t = __attribute__((address_space(3))) uint32_t;
 
-// spin until the producer's counter (wave-uniform address) has reached `want`; returns the value seen
+__device__ __forceinline__ uint32_t split_peek(lds_u32_t *cnt)     // the load only: no wait for its result here
+{
+    return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// spin until the counter (wave-uniform address) has reached `want`; returns the value seen
 __device__ __forceinline__ uint32_t split_wait(lds_u32_t *cnt, uint32_t want)
 {
-    uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    uint32_t v = __builtin_amdgcn_readfirstlane(split_peek(cnt));
     while (v < want) {
         __builtin_amdgcn_s_sleep(1);
-        v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        v = __builtin_amdgcn_readfirstlane(split_peek(cnt));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return v;
@@ -70,23 +75,22 @@ __device__ __forceinline__ void split_post(lds_u32_t *cnt, uint32_t v, unsigned 
     if (lane == 0) __hip_atomic_store(cnt, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// NP pairs of waves per block: waves [0, NP) integrate lanes base + 64 w .. + 63, wave NP + w is the helper of wave w
-// (a 512-thread block places waves w and w + 4 on the same SIMD).  Whole 64*NP-lane blocks only, auto-reset
-// handles without frozen lanes only, launch starting on an odd counter (PAIRED form): the host keeps every
-// other case on rollout_kernel.
+// NP wave triples per block: wave w < NP integrates lanes base + 64 w .. + 63, wave NP + w is their producer and
+// wave 2 NP + w their recorder (a block's waves go to the CU's four SIMDs round-robin: with NP = 4 the three
+// share one).  Whole 64*NP-lane blocks only, auto-reset handles without frozen lanes only, launch starting on an
+// odd counter (PAIRED form): the host keeps every other case on rollout_kernel.
 template <class Env, int OUT, int NP>
-__global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const RolloutArgs q)
+__global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS;
     static_assert(Env::SHARED_STEP_BLOCK && Env::COOP_RESET && !Env::CUSTOM_STEP && KS == 2 && S % 4 == 0, "written for ChemicalReactor's shape");
     using Lds = SplitLds<Env, NP>;
-    constexpr int D = Lds::D, K = Lds::K;
-    constexpr int THREADS = 128 * NP;
+    constexpr int K = Lds::K;
+    constexpr int THREADS = 192 * NP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Lds::BYTES];
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned pair = wave % NP;
-    const bool helper = wave >= NP;
+    const unsigned pair = wave % NP, role = wave / NP;          // 0 integrator, 1 producer, 2 recorder
     lds_u32_t *const sync = (lds_u32_t *)(smem + Lds::OFF_SYNC) + pair * 4;
     float *const s_hi = reinterpret_cast<float *>(smem + Lds::OFF_HI) + pair * (K * Lds::HI_SLOT);
     float *const s_ih = reinterpret_cast<float *>(smem + Lds::OFF_IH) + pair * (K * Lds::IH_SLOT);
@@ -95,22 +99,21 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
     __syncthreads();
 
     const StepArgs &p = q.s;
-    const uint32_t base = (blockIdx.x + q.block0) * (64u * NP) + pair * 64u;     // the pair's first lane
+    const uint32_t base = (blockIdx.x + q.block0) * (64u * NP) + pair * 64u;     // the triple's first lane
     const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off + (uint32_t)q.it0;   // local step i uses t_base + i + 1
     const int n = q.n_steps - q.it0;                                             // local steps [0, n)
-    const uint64_t gi = p.env0 + (uint64_t)(base + lane);
-    uint32_t ctr = (p.ctr + base)[lane];
 
-    if (!helper) {
+    if (role == 0) {
         // ------------------------------------------------------------------ integrator
         float *const s_img = reinterpret_cast<float *>(smem + Lds::OFF_IMG) + pair * (Env::RESET_ROWS * 64);
         unsigned char *const s_wlist = smem + Lds::OFF_WLIST + pair * 64;
+        uint32_t ctr = (p.ctr + base)[lane];
         float s[S], nx[S];
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[lane];
         // Inputs are read one step AHEAD: the ring counter and (speculatively) the slot of step i + 1 are read
-        // while step i is integrated; the counter is looked at afterwards, and only if the helper had not got
-        // that far (it normally is D steps ahead) the wave spins and reads the slot again.  A read issued after
+        // while step i is integrated; the counter is looked at afterwards, and only if the producer had not got
+        // that far (it normally is several steps ahead) the wave spins and reads the slot again.  A read issued after
         // the counter read sees at least what the counter promised (DS operations of a wave execute in order).
         float in[KS + A];
         auto read_inputs = [&](const int sl, float (&dst)[KS + A]) __attribute__((always_inline)) {
@@ -119,10 +122,12 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
             for (int k = 0; k < KS + A; ++k) dst[k] = hi[k * 64 + lane];
         };
         int slot = 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // state loads done: no vmcnt wait is carried into the loop
+        __builtin_amdgcn_s_setprio(3);            // the critical path of the three: the SIMD's arbiter serves this wave first
         if (n > 0) { split_wait(sync + 0, 1u); read_inputs(0, in); }
         for (int i = 0; i < n; ++i) {
             const int nslot = (slot + 1 == K) ? 0 : slot + 1;
-            const uint32_t c_next = __hip_atomic_load(sync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t c_next = split_peek(sync + 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float in_next[KS + A];
             read_inputs(nslot, in_next);
@@ -153,7 +158,7 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
             }
 #pragma unroll
             for (int k = 0; k < S; ++k) s[k] = nx[k];
-            if (i + 1 < n && __builtin_amdgcn_readfirstlane(c_next) < (uint32_t)i + 2u) {   // rare: the helper fell behind
+            if (i + 1 < n && __builtin_amdgcn_readfirstlane(c_next) < (uint32_t)i + 2u) {   // rare: the producer fell behind
                 split_wait(sync + 0, (uint32_t)i + 2u);
                 read_inputs(nslot, in_next);
             }
@@ -167,114 +172,117 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
         return;
     }
 
-    // ---------------------------------------------------------------------- helper
+    if (role == 1) {
+        // ------------------------------------------------------------------ producer
+        const uint64_t gi = p.env0 + (uint64_t)(base + lane);
+        const float *ring = p.actions + base;
+        constexpr int LA = 4;                                  // actions are loaded LA steps before they are handed on
+        float buf[LA][A];
+        uint32_t kept0 = 0u, kept1 = 0u;                       // words 2-3 of the current pair's Philox block
+        int aslot = q.it0 % q.ring_len;                        // ring slot of the action loaded next
+        const float *act_next = ring + (size_t)aslot * q.slot_stride;
+        auto load_action = [&](float (&ab)[A]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) ab[k] = (act_next + k * p.ld_act)[lane];
+            aslot = (aslot + 1 == q.ring_len) ? 0 : aslot + 1;
+            act_next = (aslot == 0) ? ring : act_next + q.slot_stride;
+        };
+        int pslot = 0;
+        uint32_t freed = 0u;                                   // slots the recorder is known to be done with
+        // slot of local step j (r = j mod LA, static: action register set and position in the pair of launch counters)
+        auto produce = [&](auto r_tag, const int j) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_tag)::value;
+            float (&ab)[A] = buf[r];
+            ProbitFetch pf[KS];
+            if constexpr ((r & 1) == 0) {         // first step of a pair: the pair's Philox block
+                const u32x4 x = Env::step_block(make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit));
+                Env::step_noise_fetch(x.x, x.y, s_probit, pf);
+                kept0 = x.z; kept1 = x.w;
+            } else {
+                Env::step_noise_fetch(kept0, kept1, s_probit, pf);
+            }
+            typename Env::fast_noise_t nz[KS];
+            Env::step_noise_eval(pf, nz);
+            float a[A];
+#pragma unroll
+            for (int k = 0; k < A; ++k) a[k] = ab[k];
+            clip_action<Env, float>(a);
+            if (freed + (uint32_t)K < (uint32_t)j + 1u) freed = split_wait(sync + 2, (uint32_t)(j + 1 - K));   // the slot's previous use
+            float *hi = s_hi + pslot * Lds::HI_SLOT;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) hi[k * 64 + lane] = (float)nz[k];    // exact: the fast-mode noise IS a float (nig_envs.hpp)
+#pragma unroll
+            for (int k = 0; k < A; ++k) hi[(KS + k) * 64 + lane] = a[k];
+            split_post(sync + 0, (uint32_t)j + 1u, lane);
+            load_action(ab);                      // this register set's next use: local step j + LA
+            pslot = (pslot + 1 == K) ? 0 : pslot + 1;
+        };
+        static_assert(LA == 4, "the loop below is written out for this depth");
+        using r0 = std::integral_constant<int, 0>; using r1 = std::integral_constant<int, 1>;
+        using r2 = std::integral_constant<int, 2>; using r3 = std::integral_constant<int, 3>;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) load_action(buf[j]);
+        int j = 0;
+        for (; j + LA <= n; j += LA) { produce(r0{}, j); produce(r1{}, j + 1); produce(r2{}, j + 2); produce(r3{}, j + 3); }
+        if (j < n) produce(r0{}, j);
+        if (j + 1 < n) produce(r1{}, j + 1);
+        if (j + 2 < n) produce(r2{}, j + 2);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- recorder
+    // Everything IndustrialEnv.step does after the dynamics (base.py:176-213), the episode bookkeeping and the outputs.
+    uint32_t ctr = (p.ctr + base)[lane];                       // mirrors the integrator's counter word
     const bool tally = p.tally != nullptr;
     using ret_t = std::conditional_t<Env::RET_F32, float, double>;
     ret_t ret = tally ? (ret_t)(p.ep_ret + base)[lane] : (ret_t)0;
     LaneTally lt;
     lt.clear();
-    const float *ring = p.actions + base;
-    float buf[D][A];
-    uint32_t kept0 = 0u, kept1 = 0u;
-    int aslot = q.it0 % q.ring_len;                            // ring slot of the action loaded next
-    const float *act_next = ring + (size_t)aslot * q.slot_stride;
-    auto load_action = [&](float (&ab)[A]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < A; ++k) ab[k] = (act_next + k * p.ld_act)[lane];
-        aslot = (aslot + 1 == q.ring_len) ? 0 : aslot + 1;
-        act_next = (aslot == 0) ? ring : act_next + q.slot_stride;
-    };
     float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
     uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
     float *obs_row = nullptr;
     if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)base * S;
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
-    int pslot = 0, cslot = 0;                                  // ring slot produced into / consumed from next
-
-    // H -> I slot of local step j (r = j mod D, static: register set and position in the pair of launch counters),
-    // in two halves so that the generator table's LDS latency lies under the work between them:
-    // first the Philox block (first step of a pair) and the table reads of the two draws ...
-    auto produce_fetch = [&](auto r_tag, const int j, ProbitFetch (&pf)[KS]) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_tag)::value;
-        if constexpr ((r & 1) == 0) {
-            const u32x4 x = Env::step_block(make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit));
-            Env::step_noise_fetch(x.x, x.y, s_probit, pf);
-            kept0 = x.z; kept1 = x.w;
-        } else {
-            Env::step_noise_fetch(kept0, kept1, s_probit, pf);
-        }
-    };
-    // ... then the normals, the clipped action, the slot and its counter, and the refill of the action registers
-    auto produce_post = [&](auto r_tag, const int j, const ProbitFetch (&pf)[KS]) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_tag)::value;
-        float (&ab)[A] = buf[r];
-        typename Env::fast_noise_t nz[KS];
-        Env::step_noise_eval(pf, nz);
-        float a[A];
-#pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = ab[k];
-        clip_action<Env, float>(a);
-        float *hi = s_hi + pslot * Lds::HI_SLOT;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) hi[k * 64 + lane] = (float)nz[k];        // exact: the fast-mode noise IS a float (nig_envs.hpp)
-#pragma unroll
-        for (int k = 0; k < A; ++k) hi[(KS + k) * 64 + lane] = a[k];
-        split_post(sync + 0, (uint32_t)j + 1u, lane);
-        load_action(ab);                          // this register set's next use: local step j + D
-        pslot = (pslot + 1 == K) ? 0 : pslot + 1;
-    };
-
-    // What the integrator left for local step i: post-dynamics state (own row and the wave's rows in
-    // lane-contiguous order), violation bits of the pre-state; and the clipped action the step was handed.
-    struct Taken { float nx[S]; float a[A]; uint32_t vb; v4f tr[S / 4]; };
-    auto take = [&](Taken &d) __attribute__((always_inline)) {
+    int cslot = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // counter / return loads done: the loop only ever stores
+    uint32_t seen = 0u;
+    for (int i = 0; i < n; ++i) {
+        if (seen < (uint32_t)i + 1u) seen = split_wait(sync + 1, (uint32_t)i + 1u);
+        // what the integrator left: post-dynamics state (own row, and the wave's rows in lane-contiguous order),
+        // violation bits of the pre-state; and the clipped action the step was handed (its P -> I slot is intact
+        // until this wave says so)
         const float *ih = s_ih + cslot * Lds::IH_SLOT;
-        const float *hi = s_hi + cslot * Lds::HI_SLOT;      // the slot this step's inputs were handed over in (still intact: K > D)
+        const float *hi = s_hi + cslot * Lds::HI_SLOT;
+        float nx[S], a[A];
         const v4f *row = reinterpret_cast<const v4f *>(ih) + lane * (S / 4);
 #pragma unroll
-        for (int k = 0; k < S / 4; ++k) { const v4f v = row[k]; d.nx[4 * k] = v.x; d.nx[4 * k + 1] = v.y; d.nx[4 * k + 2] = v.z; d.nx[4 * k + 3] = v.w; }
-        d.vb = reinterpret_cast<const uint32_t *>(ih + S * 64)[lane];
+        for (int k = 0; k < S / 4; ++k) { const v4f v = row[k]; nx[4 * k] = v.x; nx[4 * k + 1] = v.y; nx[4 * k + 2] = v.z; nx[4 * k + 3] = v.w; }
+        const uint32_t vb = reinterpret_cast<const uint32_t *>(ih + S * 64)[lane];
 #pragma unroll
-        for (int k = 0; k < A; ++k) d.a[k] = hi[(KS + k) * 64 + lane];
+        for (int k = 0; k < A; ++k) a[k] = hi[(KS + k) * 64 + lane];
+        v4f tr[S / 4];
         if constexpr (OUT == 3) {                  // see rollout_body, OUT == 3
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) d.tr[k] = reinterpret_cast<const v4f *>(ih)[lane + 64u * k];
+            for (int k = 0; k < S / 4; ++k) tr[k] = reinterpret_cast<const v4f *>(ih)[lane + 64u * k];
         }
-    };
-
-    // One helper iteration: everything IndustrialEnv.step does after the dynamics (base.py:176-213) and the outputs
-    // of local step i, around the production of step i + D (`prod`: that step exists).  The I -> H slot is read
-    // speculatively behind a read of its counter; the counter is looked at after the Philox rounds, and only if the
-    // integrator had not got that far the wave spins and reads the slot again.
-    auto hstep = [&](auto r_tag, const int i, const bool prod) __attribute__((always_inline)) {
-        const uint32_t c = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        Taken d;
-        take(d);
-        ProbitFetch pf[KS];
-        if (prod) produce_fetch(r_tag, i + D, pf);
-        if (__builtin_amdgcn_readfirstlane(c) < (uint32_t)i + 1u) {
-            split_wait(sync + 1, (uint32_t)i + 1u);
-            take(d);
-        }
+        split_post(sync + 2, (uint32_t)i + 1u, lane);          // (DS order: the reads above execute before this write)
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
-        post_core<Env, float>(d.nx, d.a, d.vb, step_pre, p.max_steps, res);
+        post_core<Env, float>(nx, a, vb, step_pre, p.max_steps, res);
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
         const bool done = res.terminated || res.truncated;
         const uint32_t fl = pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u);
         ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
         if (tally) ret = ret + (ret_t)res.reward;
-        if (prod) produce_post(r_tag, i + D, pf);
         if constexpr (OUT == 3) {
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, d.tr[k]);
+            for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, tr[k]);
         }
         if constexpr (OUT == 2) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) stream_store(obs_row + k * q.ld_obs_out + lane, d.nx[k]);
+            for (int k = 0; k < S; ++k) stream_store(obs_row + k * q.ld_obs_out + lane, nx[k]);
         }
         if constexpr (OUT >= 1) {
             stream_store(rew_row + lane, (float)res.reward);
@@ -288,32 +296,6 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
             ctr = 0u;
         }
         cslot = (cslot + 1 == K) ? 0 : cslot + 1;
-    };
-
-    static_assert(D == 4, "the loop below is written out for a run-ahead of four");
-    using r0 = std::integral_constant<int, 0>; using r1 = std::integral_constant<int, 1>;
-    using r2 = std::integral_constant<int, 2>; using r3 = std::integral_constant<int, 3>;
-#pragma unroll
-    for (int j = 0; j < D; ++j) load_action(buf[j]);           // actions of local steps 0 .. D-1
-    {
-        ProbitFetch pf[KS];
-        if (0 < n) { produce_fetch(r0{}, 0, pf); produce_post(r0{}, 0, pf); }
-        if (1 < n) { produce_fetch(r1{}, 1, pf); produce_post(r1{}, 1, pf); }
-        if (2 < n) { produce_fetch(r2{}, 2, pf); produce_post(r2{}, 2, pf); }
-        if (3 < n) { produce_fetch(r3{}, 3, pf); produce_post(r3{}, 3, pf); }
-    }
-    int i = 0;
-    for (; i + 2 * D <= n; i += D) {               // steady state: every produced step exists
-        hstep(r0{}, i, true);
-        hstep(r1{}, i + 1, true);
-        hstep(r2{}, i + 2, true);
-        hstep(r3{}, i + 3, true);
-    }
-    for (; i < n; i += D) {                        // the last one or two rounds
-        hstep(r0{}, i, i + D < n);
-        if (i + 1 < n) hstep(r1{}, i + 1, i + D + 1 < n);
-        if (i + 2 < n) hstep(r2{}, i + 2, i + D + 2 < n);
-        if (i + 3 < n) hstep(r3{}, i + 3, i + D + 3 < n);
     }
     if (lt.life != 0) (p.life_viol + base)[lane] += lt.life;
     if (tally) {
@@ -322,15 +304,15 @@ __global__ void __launch_bounds__(128 * NP, 1) split_rollout_kernel(const Rollou
     }
 }
 
-// whole blocks of 64*NP lanes, PAIRED start; the caller has checked split_rollout_ok()
+// whole blocks of 64*NP lanes, PAIRED start; the caller (launch_rollout_form) has checked that the form applies
 template <class Env, int NP>
 static void launch_split_blocks(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
     switch (out_mode) {
-    case 0: hipLaunchKernelGGL((split_rollout_kernel<Env, 0, NP>), dim3(grid), dim3(128 * NP), 0, st, q); break;
-    case 1: hipLaunchKernelGGL((split_rollout_kernel<Env, 1, NP>), dim3(grid), dim3(128 * NP), 0, st, q); break;
-    case 2: hipLaunchKernelGGL((split_rollout_kernel<Env, 2, NP>), dim3(grid), dim3(128 * NP), 0, st, q); break;
-    default: hipLaunchKernelGGL((split_rollout_kernel<Env, 3, NP>), dim3(grid), dim3(128 * NP), 0, st, q); break;
+    case 0: hipLaunchKernelGGL((split_rollout_kernel<Env, 0, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;
+    case 1: hipLaunchKernelGGL((split_rollout_kernel<Env, 1, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;
+    case 2: hipLaunchKernelGGL((split_rollout_kernel<Env, 2, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;
+    default: hipLaunchKernelGGL((split_rollout_kernel<Env, 3, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;
     }
 }
 

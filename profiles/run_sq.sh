@@ -15,7 +15,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(x in r['Kernel_Name'] for x in ('rollout_kernel', 'rollout_pair', 'step_kernel')):
+    if any(x in r['Kernel_Name'] for x in ('rollout_kernel', 'rollout_pair', 'step_kernel', 'split_rollout')):
         acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)

@@ -55,6 +55,19 @@ def test_static_queries_match_reference_constants(oracle):
     assert L.nig_env_id(b"nope") == -1
 
 
+def test_tune_knob_needs_no_gpu():
+    """nig_tune / nig_tune_get: pure host state (include/nig.h)."""
+    import neorl_industrial_gym_amd as ni
+    _lib = ni._lib
+    L = _lib.lib()
+    before = L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS)
+    assert before >= 0 and L.nig_tune_get(99) == -1
+    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, 12) == 0 and L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == 12
+    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, -1) != 0 and L.nig_tune(99, 1) != 0
+    assert L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == 12
+    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, before) == 0
+
+
 def test_layout_query():
     import neorl_industrial_gym_amd as ni
     lay = ni._lib.layout_query(1, 1000, ni._lib.F_TALLY)

@@ -1,0 +1,113 @@
+"""-m gpu: the three-wave form of the ChemicalReactor rollout (csrc/nig_split.hpp: producer / integrator /
+recorder wave per 64 lanes, used for batches of up to one 256-lane block per CU) against the one-wave
+rollout_kernel on the same inputs.  Everything a rollout leaves behind must be bit-identical: per-step reward /
+flag rows, both trajectory layouts, final state, counter words, lifetime violations, running returns, tallies."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAME = "ChemicalReactor-v0"
+
+
+@pytest.fixture(scope="module")
+def ni():
+    import neorl_industrial_gym_amd as ni
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    yield ni
+    ni.tune(split_blocks=256)
+
+
+def _ring(env, R, t0=70):
+    ring = torch.empty(R, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
+    for s in range(R):
+        env.fill_actions(t0 + s, ring[s])
+    return ring
+
+
+def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11):
+    """Roll `chunks` (list of step counts) through one handle; returns every observable as CPU tensors."""
+    ni.tune(split_blocks=256 if split else 0)
+    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
+    ring = _ring(env, R)
+    env.reset()
+    env.counter = first_counter
+    got = []
+    for T in chunks:
+        rew = fl = obs = None
+        if outputs != "none":
+            rows = () if outputs == "last" else (T,)
+            rew = torch.full(rows + (env.ld,), float("nan"), dtype=torch.float32, device=env.device)
+            fl = torch.zeros(rows + (env.ld,), dtype=torch.int32, device=env.device)
+        if outputs == "aos":
+            obs = torch.full((T, B, env.state_dim), float("nan"), dtype=torch.float32, device=env.device)
+        elif outputs == "soa":
+            obs = torch.full((T, env.state_dim, env.ld), float("nan"), dtype=torch.float32, device=env.device)
+        env.rollout(T, ring, rew, fl, obs)
+        torch.cuda.synchronize()
+        for t in (rew, fl, obs):
+            if t is not None:
+                got.append(t[..., :B].cpu() if t is not obs or outputs == "soa" else t.cpu())
+    got += [env.state_soa.cpu(), env.ctr.cpu(), env.life_viol.cpu(), env.ep_return.cpu(), env.tally.cpu()]
+    counter = env.counter
+    env.close()
+    return got, counter
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and x.dtype == y.dtype, i
+        xv = x.contiguous().view(torch.int32) if x.dtype == torch.float32 else (x.contiguous().view(torch.int64) if x.dtype == torch.float64 else x)
+        yv = y.contiguous().view(torch.int32) if y.dtype == torch.float32 else (y.contiguous().view(torch.int64) if y.dtype == torch.float64 else y)
+        assert torch.equal(xv, yv), f"observable {i} differs"
+
+
+@pytest.mark.parametrize("outputs", ["none", "last", "rows", "soa", "aos"])
+@pytest.mark.parametrize("B", [1024, 2500])
+def test_split_form_equals_one_wave_form(ni, outputs, B):
+    """Whole blocks (1024) and whole blocks + a ragged tail launch (2500); 41 steps over a 7-slot ring with
+    20-step episodes: ring wrap, truncations, terminations and in-kernel resets all occur."""
+    kw = dict(B=B, chunks=[41], outputs=outputs, R=7, max_steps=20)
+    a, ca = _run(ni, True, **kw)
+    b, cb = _run(ni, False, **kw)
+    assert ca == cb == 41
+    _same(a, b)
+    assert float(a[-1][0].sum()) > 0          # episodes finished and were tallied
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 4, 5, 6, 7, 9, 13])
+def test_split_form_short_and_odd_lengths(ni, n_steps):
+    """Launches shorter than the producer's look-ahead and every remainder of its unrolled loop."""
+    kw = dict(B=512, chunks=[n_steps], outputs="aos", R=3, max_steps=4)
+    a, _ = _run(ni, True, **kw)
+    b, _ = _run(ni, False, **kw)
+    _same(a, b)
+
+
+@pytest.mark.parametrize("first_counter", [0, 1, 6, 7])
+def test_split_form_chunked_and_misaligned_starts(ni, first_counter):
+    """Consecutive launches on one handle (state, counters and running returns carried over) starting on odd
+    and even launch counters: an even start peels one step into the one-wave form first."""
+    kw = dict(B=768, chunks=[5, 1, 8, 2, 11], outputs="rows", R=5, max_steps=9, first_counter=first_counter)
+    a, ca = _run(ni, True, **kw)
+    b, cb = _run(ni, False, **kw)
+    assert ca == cb == first_counter + 27
+    _same(a, b)
+
+
+def test_split_form_at_the_headline_batch(ni):
+    """65 536 lanes x 250 steps, default 500-step episodes, row-major trajectory: the benchmark's launch."""
+    kw = dict(B=65536, chunks=[250], outputs="aos", R=16, max_steps=None)
+    a, _ = _run(ni, True, **kw)
+    b, _ = _run(ni, False, **kw)
+    _same(a, b)
+
+
+def test_tune_knob_roundtrip(ni):
+    assert ni.tune(split_blocks=17)["split_blocks"] == 17
+    assert ni.tune()["split_blocks"] == 17
+    with pytest.raises(Exception):
+        ni.tune(split_blocks=-1)
+    assert ni.tune(split_blocks=256)["split_blocks"] == 256
