@@ -148,6 +148,16 @@ def timed(torch, dist, world, comm_dev, wl, K, W):
     return float(tm[0].item()), float(tm[1].item())
 
 
+def rollout_kernel_name(wl):
+    """The kernel nig_rollout launches for this workload (csrc/nig_kernels.hpp launch_rollout_form): ChemicalReactor
+    batches of whole 256-lane blocks, up to nig_tune(NIG_TUNE_SPLIT_BLOCKS) of them, run in the three-wave form."""
+    out = {"none": 0, "min": 1, "full": 3}[wl.outputs]
+    blocks = wl.B // 256
+    if wl.key == "cr" and wl.B % 256 == 0 and 0 < blocks <= wl.ni.tune()["split_blocks"]:
+        return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
+    return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
+
+
 def roofline_of(wl, K, dev_ms):
     rollout = wl.mode == "rollout"
     bytes_step = alg_bytes_rollout(wl.S, wl.A, wl.outputs) if rollout else alg_bytes_per_step(wl.S, wl.A)
@@ -160,8 +170,7 @@ def roofline_of(wl, K, dev_ms):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None if per_step is None else per_step * env_steps_per_kernel,
             "traffic_bytes_per_env_step": per_step, "traffic_source": src,
-            "kernel": ("rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], {"none": 0, "min": 1, "full": 3}[wl.outputs])
-                       if rollout else "step_kernel<%s,false>" % KERNEL_ENV[wl.key]),
+            "kernel": (rollout_kernel_name(wl) if rollout else "step_kernel<%s,false>" % KERNEL_ENV[wl.key]),
             "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_kernel,
             "alg_bytes_per_launch": alg, "launch_us": kernel_us, "launches_timed": n_kernels,
             "bytes_model": ("fused-rollout figure (SURVEY 8d): action read + requested per-step outputs"

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         // ------------------------------------------------------------------ integrator
         float *const s_img = reinterpret_cast<float *>(smem + Lds::OFF_IMG) + pair * (Env::RESET_ROWS * 64);
         unsigned char *const s_wlist = smem + Lds::OFF_WLIST + pair * 64;
-        uint32_t ctr = (p.ctr + base)[lane];
+        int step = (int)((p.ctr + base)[lane] & NIG_CTR_STEP_MASK);     // the recorder keeps (and stores) the whole counter word
         float s[S], nx[S];
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[lane];
@@ -115,21 +115,18 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         // while step i is integrated; the counter is looked at afterwards, and only if the producer had not got
         // that far (it normally is several steps ahead) the wave spins and reads the slot again.  A read issued after
         // the counter read sees at least what the counter promised (DS operations of a wave execute in order).
-        float in[KS + A];
+        // Two input register sets, the loop unrolled by two: no copies between them.
+        float in0[KS + A], in1[KS + A];
         auto read_inputs = [&](const int sl, float (&dst)[KS + A]) __attribute__((always_inline)) {
             const float *hi = s_hi + sl * Lds::HI_SLOT;
 #pragma unroll
             for (int k = 0; k < KS + A; ++k) dst[k] = hi[k * 64 + lane];
         };
         int slot = 0;
-        __builtin_amdgcn_s_waitcnt(0x0F70);       // state loads done: no vmcnt wait is carried into the loop
-        __builtin_amdgcn_s_setprio(3);            // the critical path of the three: the SIMD's arbiter serves this wave first
-        if (n > 0) { split_wait(sync + 0, 1u); read_inputs(0, in); }
-        for (int i = 0; i < n; ++i) {
+        auto integrate = [&](const float (&in)[KS + A], float (&in_next)[KS + A], const int i) __attribute__((always_inline)) {
             const int nslot = (slot + 1 == K) ? 0 : slot + 1;
             const uint32_t c_next = split_peek(sync + 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float in_next[KS + A];
             read_inputs(nslot, in_next);
             double nz[KS];
             float a[A];
@@ -137,11 +134,10 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             for (int k = 0; k < KS; ++k) nz[k] = (double)in[k];
 #pragma unroll
             for (int k = 0; k < A; ++k) a[k] = in[KS + k];
-            const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
             const uint32_t vb = Env::violated(s, a) & p.cmask;
             Env::dynamics(s, a, nz, p.dt32, p.dt, nx);
             StepResult<Env> res;
-            post_core<Env, float>(nx, a, vb, step_pre, p.max_steps, res);      // the reward part is dead here
+            post_core<Env, float>(nx, a, vb, step, p.max_steps, res);          // the reward part is dead here
             const bool done = res.terminated || res.truncated;
             float *ih = s_ih + slot * Lds::IH_SLOT;
             v4f *row = reinterpret_cast<v4f *>(ih) + lane * (S / 4);
@@ -149,26 +145,27 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             for (int k = 0; k < S / 4; ++k) { v4f v = {nx[4 * k], nx[4 * k + 1], nx[4 * k + 2], nx[4 * k + 3]}; row[k] = v; }
             reinterpret_cast<uint32_t *>(ih + S * 64)[lane] = vb;
             split_post(sync + 1, (uint32_t)i + 1u, lane);
-            ctr = (uint32_t)(step_pre + 1) | (((ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol) << NIG_CTR_VIOL_SHIFT);
+            step = done ? 0 : step + 1;
             const unsigned long long m = __ballot(done);
-            if (m != 0ull) {
+            if (m != 0ull)
                 coop_reset<Env>(m, done, lane, s_img, s_wlist, p.env0 + (uint64_t)base, t_base + (uint32_t)i + 1u,
                                 p.seed_lo, p.seed_hi, s_probit, nx);
-                if (done) ctr = 0u;
-            }
 #pragma unroll
             for (int k = 0; k < S; ++k) s[k] = nx[k];
             if (i + 1 < n && __builtin_amdgcn_readfirstlane(c_next) < (uint32_t)i + 2u) {   // rare: the producer fell behind
                 split_wait(sync + 0, (uint32_t)i + 2u);
                 read_inputs(nslot, in_next);
             }
-#pragma unroll
-            for (int k = 0; k < KS + A; ++k) in[k] = in_next[k];
             slot = nslot;
-        }
+        };
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // state loads done: no vmcnt wait is carried into the loop
+        __builtin_amdgcn_s_setprio(3);            // the critical path of the three: the SIMD's arbiter serves this wave first
+        if (n > 0) { split_wait(sync + 0, 1u); read_inputs(0, in0); }
+        int i = 0;
+        for (; i + 2 <= n; i += 2) { integrate(in0, in1, i); integrate(in1, in0, i + 1); }
+        if (i < n) integrate(in0, in1, i);
 #pragma unroll
         for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[lane] = s[k];
-        (p.ctr + base)[lane] = ctr;
         return;
     }
 
@@ -297,6 +294,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         }
         cslot = (cslot + 1 == K) ? 0 : cslot + 1;
     }
+    (p.ctr + base)[lane] = ctr;
     if (lt.life != 0) (p.life_viol + base)[lane] += lt.life;
     if (tally) {
         (p.ep_ret + base)[lane] = (double)ret;
