@@ -1,0 +1,2 @@
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/r02_gpu_tests_11.log 2>&1; tail -25 gpurun_out/r02_gpu_tests_11.log

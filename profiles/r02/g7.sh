@@ -1,0 +1,3 @@
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/r02_gpu_tests_7.log 2>&1; tail -5 gpurun_out/r02_gpu_tests_7.log
+bash profiles/ab.sh "coop2 coop3" "pg 262144 full aos" "pg 262144 full aos --mode graph --plan-steps 50" "ra 262144 full aos --mode graph --plan-steps 50" 2>&1 | tee gpurun_out/r02_ab_pg3.log
