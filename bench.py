@@ -8,7 +8,9 @@ One bench "step" = ONE PASS of the hot path over the batch = one fused launch th
 --plan-steps (default 250) consecutive IndustrialEnv.step() calls of every lane (the shape of
 the reference's own measurement loop, performance_benchmark.py:106-133: act -> step -> reset on
 done).  K timed launches, W untimed; `ms_per_step` is per launch; `config.env_steps_per_step`
-= plan_steps x batch; `value` = K x plan_steps x batch x N / wall.
+= plan_steps x batch; `value` = K x plan_steps x batch x N / wall.  Before the W warm-up launches the same
+workload runs untimed for --settle seconds (default 0.6): after idle the GPU needs ~0.2 s of sustained load
+to reach its steady state (profiles/r02/runlength_probe.txt), and the metric is sustained throughput.
 
 Workload at N=1 = BASELINE.json configs[1]: ChemicalReactor-v0, 65536 parallel envs, uniform
 random float32 actions from a pre-filled on-device ring, process noise and auto-reset drawn
@@ -123,9 +125,26 @@ class Workload:
         self.env.close()
 
 
-def timed(torch, dist, world, comm_dev, wl, K, W):
-    """W untimed + exactly K timed launches, bracketed by barrier + synchronize on both sides;
-    HIP events on the launch stream around the same region.  Returns (wall s, device ms): max over ranks."""
+def settle(torch, wl, seconds):
+    """Untimed: run the workload back to back for `seconds` before the W warm-up launches.  After an idle phase
+    (process start, buffer setup) this GPU takes ~0.1-0.2 s of sustained load to reach its steady state: the first
+    20 launches of the headline rollout take 235 us each, launches 1000+ take 175 us (profiles/r02/runlength_probe.txt).
+    The metric is sustained throughput, so the ramp is kept out of the timed region.  Returns the launches run."""
+    n = 0
+    if seconds > 0:
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            for _ in range(32):
+                wl.launch()
+            torch.cuda.synchronize()
+            n += 32
+    return n
+
+
+def timed(torch, dist, world, comm_dev, wl, K, W, settle_s=0.0):
+    """[settle_s of untimed load,] W untimed + exactly K timed launches, bracketed by barrier + synchronize on both
+    sides; HIP events on the launch stream around the same region.  Returns (wall s, device ms): max over ranks."""
+    settle(torch, wl, settle_s)
     for _ in range(W):
         wl.launch()
     torch.cuda.synchronize()
@@ -265,6 +284,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed launches (one launch = --plan-steps env.step of every lane)")
     ap.add_argument("--warmup", type=int, default=20, help="untimed launches")
+    ap.add_argument("--settle", type=float, default=0.6,
+                    help="seconds of untimed back-to-back load before the warm-up launches (clock / memory-side ramp after idle)")
     ap.add_argument("--env", default="cr", choices=list(ENVS) + ["mixed"],
                     help="mixed = all env types in one padded SoA batch (BASELINE config 4), rollout mode, min outputs")
     ap.add_argument("--batch", type=int, default=0, help="lanes per GPU (default: BASELINE config of --env)")
@@ -349,7 +370,7 @@ def main():
         Bp = BASELINE_BATCH["pg"]
         w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, min(args.ring, 16), args.outputs, args.traj)
         K3 = max(2, min(K, 8))
-        pw, pd = timed(torch, dist, world, comm_dev, w3, K3, 2)
+        pw, pd = timed(torch, dist, world, comm_dev, w3, K3, 2, args.settle)
         r3 = roofline_of(w3, K3, pd)
         ptotal, pcheck = gathered_tally(torch, dist, world, comm_dev, w3)
         L = ni._lib
@@ -363,7 +384,7 @@ def main():
 
     # ---- headline: workload resident in HBM before the timed region
     wl = Workload(ni, torch, key, B, device, rank, args.mode, P, args.ring, args.outputs, args.traj)
-    wall, dev_ms = timed(torch, dist, world, comm_dev, wl, K, W)
+    wall, dev_ms = timed(torch, dist, world, comm_dev, wl, K, W, args.settle)
     roof = roofline_of(wl, K, dev_ms)
     total, tally_check = gathered_tally(torch, dist, world, comm_dev, wl)
 
@@ -392,6 +413,7 @@ def main():
                                       f"{P} step-API launches (one fused step kernel per env.step), {args.mode}"),
                        "batch_per_gpu": B, "global_batch": B * world, "plan_steps": P, "env_steps_per_step": P * B * world,
                        "action_ring": args.ring, "autoreset": True, "episode_tally": True,
+                       "settle_seconds": args.settle,
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
             "roofline": roof,
             "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
@@ -453,7 +475,7 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
     class _W:
         def launch(self):
             mix.rollout(P, ring, rew, fl)
-    wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W)
+    wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W, args.settle)
     # per-env rate measured separately on its own segment size (same per-env kernels, stand-alone launch)
     per_env = {}
     for (name, n), seg, o in zip(counts, mix.envs, mix.offsets):
