@@ -132,8 +132,9 @@ const char *nig_last_error(void);
  * bit-identical (tests/test_gpu_split.py).  No counterpart upstream.
  *   NIG_TUNE_SPLIT_BLOCKS   largest batch, in 256-lane blocks, that nig_rollout runs in the three-wave form
  *                           (csrc/nig_split.hpp: producer / integrator / recorder wave per 64 ChemicalReactor
- *                           lanes); default 256 = one block per CU, 0 = never.  The environment variable
- *                           NIG_SPLIT_BLOCKS sets the initial value.
+ *                           lanes); default = one block per compute unit of the device
+ *                           the first handle is created on (256 on an MI355X), 0 = never.  The environment
+ *                           variable NIG_SPLIT_BLOCKS sets the initial value.
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
 enum { NIG_TUNE_SPLIT_BLOCKS = 0 };
 int nig_tune(int32_t key, int64_t value);

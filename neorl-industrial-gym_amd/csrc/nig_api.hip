@@ -237,10 +237,22 @@ static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, h
 }
 
 namespace nig {
+// Largest batch, in 256-lane blocks, that runs in the three-wave form.  Default: one block per compute unit of the
+// device the first handle was created on (256 on an MI355X in SPX mode); NIG_SPLIT_BLOCKS / nig_tune override it.
+static bool g_split_explicit = false;
 unsigned g_split_blocks = [] {
     const char *e = getenv("NIG_SPLIT_BLOCKS");
-    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;        // one 256-lane block per CU
+    if (e) g_split_explicit = true;
+    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
 }();
+static void split_default_from_device(int device)
+{
+    static bool done = false;
+    if (done || g_split_explicit) return;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_split_blocks = (unsigned)cus;
+    done = true;
+}
 }
 
 extern "C" {
@@ -252,6 +264,7 @@ int nig_tune(int32_t key, int64_t value)
 {
     if (key != NIG_TUNE_SPLIT_BLOCKS || value < 0 || value > 0x7fffffffLL) return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
     nig::g_split_blocks = (unsigned)value;
+    nig::g_split_explicit = true;
     return NIG_OK;
 }
 int64_t nig_tune_get(int32_t key) { return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::g_split_blocks : -1; }
@@ -322,6 +335,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device < 0 || device >= ndev) return fail(NIG_ERR_INVALID, "nig_create: device index out of range%s");
     HIP_TRY(hipSetDevice(device));
+    split_default_from_device(device);
 
     nig_handle *h = new (std::nothrow) nig_handle();
     if (!h) return fail(NIG_ERR_INVALID, "nig_create: out of host memory%s");
