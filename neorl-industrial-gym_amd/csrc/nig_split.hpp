@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
     constexpr int THREADS = 192 * NP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Lds::BYTES];
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    // readfirstlane: the wave index (and everything derived from it: role, ring addresses, row pointers) lives in
+    // scalar registers -- the role branches are scalar branches and the row pointers advance on the scalar unit
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned pair = wave % NP, role = wave / NP;          // 0 integrator, 1 producer, 2 recorder
     lds_u32_t *const sync = (lds_u32_t *)(smem + Lds::OFF_SYNC) + pair * 4;
     float *const s_hi = reinterpret_cast<float *>(smem + Lds::OFF_HI) + pair * (K * Lds::HI_SLOT);
