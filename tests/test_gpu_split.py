@@ -26,10 +26,12 @@ def _ring(env, R, t0=70):
     return ring
 
 
-def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11):
+def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11, tally=True, env_index0=0, cmask=None):
     """Roll `chunks` (list of step counts) through one handle; returns every observable as CPU tensors."""
     ni.tune(split_blocks=256 if split else 0)
-    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
+    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=tally, max_episode_steps=max_steps, env_index0=env_index0)
+    if cmask is not None:
+        env.set_constraint_mask(cmask)
     ring = _ring(env, R)
     env.reset()
     env.counter = first_counter
@@ -49,7 +51,9 @@ def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11):
         for t in (rew, fl, obs):
             if t is not None:
                 got.append(t[..., :B].cpu() if t is not obs or outputs == "soa" else t.cpu())
-    got += [env.state_soa.cpu(), env.ctr.cpu(), env.life_viol.cpu(), env.ep_return.cpu(), env.tally.cpu()]
+    got += [env.state_soa.cpu(), env.ctr.cpu(), env.life_viol.cpu()]
+    if tally:
+        got += [env.ep_return.cpu(), env.tally.cpu()]
     counter = env.counter
     env.close()
     return got, counter
@@ -94,6 +98,17 @@ def test_split_form_chunked_and_misaligned_starts(ni, first_counter):
     a, ca = _run(ni, True, **kw)
     b, cb = _run(ni, False, **kw)
     assert ca == cb == first_counter + 27
+    _same(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(tally=False), dict(env_index0=3 * 65536 + 512, seed=0xABCDEF), dict(cmask=0b101),
+                                dict(cmask=0)], ids=["no_tally", "shard_offset", "mask_101", "mask_none"])
+def test_split_form_handle_variants(ni, kw):
+    """Handles without the episode tally, lanes keyed at a shard offset, handles with constraints removed
+    (base.py:224-228): the three-wave form reads the same handle state as the one-wave form."""
+    args = dict(B=1024, chunks=[23, 10], outputs="aos", R=6, max_steps=12, **kw)
+    a, _ = _run(ni, True, **args)
+    b, _ = _run(ni, False, **args)
     _same(a, b)
 
 
