@@ -827,6 +827,8 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 }  // namespace nig
 #include "nig_split.hpp"
 namespace nig {
+// Largest batch (in 256-lane blocks) the three-wave forms are used for (nig_tune(NIG_TUNE_SPLIT_BLOCKS); nig_api.hip).
+extern unsigned g_split_blocks;
 
 // Mixed-batch launch (nig_mixed.hip): per-segment rollout arguments + the block -> segment table, in launch order.
 constexpr int MIXED_MAX_SEG = NIG_MIXED_MAX_SEGMENTS;
@@ -853,6 +855,133 @@ struct PolicyArgs {
     float *act_out; uint32_t ld_act_out; uint64_t act_step_stride;   // [A][ld] per step
 };
 
+// The policy's random draws of one step: they depend on the lane's key only, not on the observation, so the
+// three-wave form (nig_split.hpp) produces them ahead of the step that consumes them.
+template <int A>
+struct PolicyDraws { float z[A], h[A], ra[A], wmix; };
+
+// Register copy of the policy fields an env of this size reads, for a wave that evaluates the feedback law on its
+// critical path (the integrator of nig_split_policy.hpp): read in place from LDS, every observation column is one
+// exposed ds_read round trip per step.  Same field names as nig_policy: policy_apply takes either.
+template <class Env>
+struct PolicyRegs {
+    static constexpr int S = Env::S, A = Env::A;
+    int32_t kind; uint32_t colmask;
+    float Wt[S][A], b[A], sigma[A], half_range[A], setpoint[A];
+    float p_uniform, uniform_range, clip_lo, clip_hi, kp, ki, kd;
+    // (vector registers: as scalars they spill -- 36 weights + 19 other fields against ~100 SGPRs -- and every use of a
+    // spilled one costs a v_readlane; the kernel's three waves per SIMD leave each 168 VGPRs)
+    __device__ static float sreg(float v) { return v; }
+    __device__ __forceinline__ void load(const nig_policy &P)
+    {
+        kind = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)P.kind);
+        colmask = __builtin_amdgcn_readfirstlane(P.colmask);
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+#pragma unroll
+            for (int j = 0; j < A; ++j) Wt[k][j] = sreg(P.Wt[k][j]);
+#pragma unroll
+        for (int j = 0; j < A; ++j) { b[j] = sreg(P.b[j]); sigma[j] = sreg(P.sigma[j]); half_range[j] = sreg(P.half_range[j]); setpoint[j] = sreg(P.setpoint[j]); }
+        p_uniform = sreg(P.p_uniform); uniform_range = sreg(P.uniform_range); clip_lo = sreg(P.clip_lo); clip_hi = sreg(P.clip_hi);
+        kp = sreg(P.kp); ki = sreg(P.ki); kd = sreg(P.kd);
+    }
+};
+
+template <int A, class PV>
+__device__ __forceinline__ void policy_switches(const PV *__restrict__ P, bool &any_sigma, bool &any_half, bool &mix)
+{
+    any_sigma = false; any_half = false;
+#pragma unroll
+    for (int j = 0; j < A; ++j) { any_sigma = any_sigma || (P->sigma[j] != 0.0f); any_half = any_half || (P->half_range[j] != 0.0f); }
+    mix = P->p_uniform > 0.0f;
+}
+
+template <class Env>
+__device__ __forceinline__ void policy_draws(const nig_policy *__restrict__ P, const RngKey &key, PolicyDraws<Env::A> &d)
+{
+    constexpr int A = Env::A;
+    bool any_sigma, any_half, mix;
+    policy_switches<A>(P, any_sigma, any_half, mix);
+    if (any_sigma) gen_normals<A>(key, STREAM_POLICY + 1u, d.z);
+    if (any_half) {
+#pragma unroll
+        for (int b4 = 0; 4 * b4 < A; ++b4) {
+            const u32x4 x = key.block(STREAM_POLICY + 8u + (uint32_t)b4);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * b4 + i < A) d.h[4 * b4 + i] = 2.0f * u01f(w[i]) - 1.0f;
+        }
+    }
+    if (mix) {
+        d.wmix = u01f(key.block(STREAM_POLICY).x);
+        const float r = P->uniform_range;
+#pragma unroll
+        for (int b4 = 0; 4 * b4 < A; ++b4) {
+            const u32x4 x = key.block(STREAM_POLICY + 16u + (uint32_t)b4);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * b4 + i < A) d.ra[4 * b4 + i] = r * (2.0f * u01f(w[i]) - 1.0f);
+        }
+    }
+}
+
+// feedback law on the observation + the draws + the policy's own clip (include/nig.h "nig-policy-v1")
+template <class Env, class PV>
+__device__ __forceinline__ void policy_apply(const PV *__restrict__ P, const float (&obs)[Env::S],
+                                             const PolicyDraws<Env::A> &d, float (&integ)[Env::A], float (&eprev)[Env::A],
+                                             float (&u)[Env::A])
+{
+    constexpr int S = Env::S, A = Env::A;
+    if (P->kind == NIG_POLICY_PID) {               // baseline_agents.py:61-80
+        const float kp = P->kp, ki = P->ki, kd = P->kd;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float e = P->setpoint[j] - obs[j];
+            integ[j] = integ[j] + e;
+            u[j] = (kp * e + ki * integ[j]) + kd * (e - eprev[j]);
+            eprev[j] = e;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = P->b[j];
+        const uint32_t cm = P->colmask;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            if (cm & (1u << k)) {                  // wave-uniform: whole zero columns are skipped
+#pragma unroll
+                for (int j = 0; j < A; ++j) u[j] = u[j] + P->Wt[k][j] * obs[k];
+            }
+        }
+    }
+    bool any_sigma, any_half, mix;
+    policy_switches<A>(P, any_sigma, any_half, mix);
+    if (any_sigma) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = u[j] + P->sigma[j] * d.z[j];
+    }
+    if (any_half) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = u[j] + P->half_range[j] * d.h[j];
+    }
+    if (mix) {
+        const bool rnd = d.wmix < P->p_uniform;
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[j] = rnd ? d.ra[j] : u[j];
+    }
+    const float lo = P->clip_lo, hi = P->clip_hi;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {                  // np.clip == minimum(maximum(x, lo), hi)
+        float x = u[j];
+        x = (x < lo) ? lo : x;
+        x = (x > hi) ? hi : x;
+        u[j] = x;
+    }
+}
+
+// The one-wave kernel's form of the same policy: draws interleaved with their use (shorter live ranges than
+// policy_draws + policy_apply; the two forms are pinned against each other by tests/test_gpu_split.py).
 template <class Env>
 __device__ __forceinline__ void policy_action(const nig_policy *__restrict__ P, const float (&obs)[Env::S],
                                               const RngKey &key, float (&integ)[Env::A], float (&eprev)[Env::A],
@@ -1086,6 +1215,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
         }
     }
 }
+
+}  // namespace nig
+#include "nig_split_policy.hpp"
+namespace nig {
 
 // ------------------------------------------------------------------------------------------
 // Fused MLP actor + env step (the one contraction on this path, so the one place for MFMA).
@@ -1417,9 +1550,6 @@ static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned g
     }
 }
 
-// Largest batch (in 256-lane blocks) the three-wave form is used for (nig_tune(NIG_TUNE_SPLIT_BLOCKS); nig_api.hip).
-extern unsigned g_split_blocks;
-
 // the batch's whole 256-lane blocks in one launch without lane predication, a ragged last block in its own
 template <class Env, bool PAIRED>
 static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*grid*/, hipStream_t st)
@@ -1462,6 +1592,14 @@ static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, 
 template <class Env>
 static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
 {
+    if constexpr (split_rollout<Env>::value) {
+        // batches that leave one wave per SIMD: producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp)
+        const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+        if (plain && q.s.B % BLOCK == 0 && q.s.B / BLOCK <= g_split_blocks) {
+            hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(q.s.B / BLOCK), dim3(192 * (BLOCK / 64)), 0, st, q);
+            return;
+        }
+    }
     hipLaunchKernelGGL((rollout_policy_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, q);
 }
 

@@ -1,0 +1,251 @@
+// nig_split_policy.hpp -- the closed-loop (device policy) rollout in the three-wave form of nig_split.hpp
+// (included by nig_kernels.hpp behind rollout_policy_kernel; same batches: ChemicalReactor, whole 256-lane blocks,
+// up to one block per CU, auto-reset handle without frozen lanes).
+//
+// What changes against the open-loop form: the action is a function of the state, so it cannot be produced ahead.
+//   producer   : process noise of the step + the policy's own random draws (exploration normals, uniform
+//                perturbation, epsilon-mix draw and its uniform action: policy_draws) -- everything that depends
+//                on the lane's key only.  No global memory access at all.
+//   integrator : policy_apply on its state (feedback law + the draws + the policy's clip; PID memory lives in
+//                its registers), then the step as before.  Leaves the observation it acted on, the post-dynamics
+//                state, the violation bits and the policy's action.
+//   recorder   : reward / flags / tally as before, plus the transition stream the caller asked for (observation
+//                acted on, row-major through the transposing image; the policy's action rows).
+// Bit-identical to rollout_policy_kernel (tests/test_gpu_split.py).
+#pragma once
+
+namespace nig {
+
+template <class Env, int NP>
+struct SplitPolicyLds {
+    static constexpr int K = 3;                                        // ring slots
+    static constexpr int HI_ROWS = Env::KS + 3 * Env::A + 1;           // noise, z, h, ra, wmix
+    static constexpr int HI_SLOT = HI_ROWS * 64;                       // floats
+    static constexpr int IH_SLOT = (2 * Env::S + 1 + Env::A) * 64;     // [64][S] observation acted on, [64][S] post-dynamics state, violation words, [A][64] action
+    static constexpr int OFF_PROBIT = 0;
+    static constexpr int OFF_POL = 768 * 16;
+    static constexpr int OFF_IMG = OFF_POL + (int)((sizeof(nig_policy) + 15) / 16 * 16);
+    static constexpr int OFF_WLIST = OFF_IMG + NP * Env::RESET_ROWS * 64 * 4;
+    static constexpr int OFF_SYNC = OFF_WLIST + NP * 64;
+    static constexpr int OFF_HI = OFF_SYNC + NP * 16;
+    static constexpr int OFF_IH = OFF_HI + NP * K * HI_SLOT * 4;
+    static constexpr int BYTES = OFF_IH + NP * K * IH_SLOT * 4;
+    static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+};
+
+template <class Env, int NP>
+__global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyArgs q)
+{
+    constexpr int S = Env::S, A = Env::A, KS = Env::KS;
+    static_assert(Env::SHARED_STEP_BLOCK && Env::COOP_RESET && !Env::CUSTOM_STEP && KS == 2 && S % 4 == 0, "written for ChemicalReactor's shape");
+    using Lds = SplitPolicyLds<Env, NP>;
+    constexpr int K = Lds::K;
+    constexpr int THREADS = 192 * NP;
+    constexpr int ROW_Z = KS, ROW_H = KS + A, ROW_RA = KS + 2 * A, ROW_MIX = KS + 3 * A;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Lds::BYTES];
+    float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
+    const nig_policy *const pol = reinterpret_cast<const nig_policy *>(smem + Lds::OFF_POL);
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned pair = wave % NP, role = wave / NP;          // 0 integrator, 1 producer, 2 recorder
+    lds_u32_t *const sync = (lds_u32_t *)(smem + Lds::OFF_SYNC) + pair * 4;
+    float *const s_hi = reinterpret_cast<float *>(smem + Lds::OFF_HI) + pair * (K * Lds::HI_SLOT);
+    float *const s_ih = reinterpret_cast<float *>(smem + Lds::OFF_IH) + pair * (K * Lds::IH_SLOT);
+    for (int i_ = (int)tid; i_ < 768; i_ += THREADS) s_probit[i_] = NIG_PROBIT[i_];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem + Lds::OFF_POL);
+        for (unsigned i_ = tid; i_ < sizeof(nig_policy) / 4; i_ += THREADS) dst[i_] = src[i_];
+    }
+    if (tid < NP * 4) reinterpret_cast<uint32_t *>(smem + Lds::OFF_SYNC)[tid] = 0u;
+    __syncthreads();
+
+    const StepArgs &p = q.s;
+    const uint32_t base = blockIdx.x * (64u * NP) + pair * 64u;      // the triple's first lane
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;     // step i uses t_base + i + 1
+    const int n = q.n_steps;
+    bool any_sigma, any_half, mix;                                   // wave-uniform switches of the policy
+    policy_switches<A>(pol, any_sigma, any_half, mix);
+
+    if (role == 1) {
+        // ------------------------------------------------------------------ producer
+        const uint64_t gi = p.env0 + (uint64_t)(base + lane);
+        u32x4 blk = {0u, 0u, 0u, 0u};
+        int pslot = 0;
+        uint32_t freed = 0u;
+        for (int j = 0; j < n; ++j) {
+            const RngKey key = make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit);
+            const bool second = (key.t & 1u) == 0u;                  // launch counters 2k-1, 2k share one Philox block (draw_step)
+            if (!second || j == 0) blk = Env::step_block(key);
+            typename Env::fast_noise_t nz[KS];
+            Env::step_noise(second ? blk.z : blk.x, second ? blk.w : blk.y, s_probit, nz);
+            PolicyDraws<A> d;
+            policy_draws<Env>(pol, key, d);
+            if (freed + (uint32_t)K < (uint32_t)j + 1u) freed = split_wait(sync + 2, (uint32_t)(j + 1 - K));
+            float *hi = s_hi + pslot * Lds::HI_SLOT;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) hi[k * 64 + lane] = (float)nz[k];    // exact: the fast-mode noise IS a float
+            if (any_sigma) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) hi[(ROW_Z + k) * 64 + lane] = d.z[k];
+            }
+            if (any_half) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) hi[(ROW_H + k) * 64 + lane] = d.h[k];
+            }
+            if (mix) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) hi[(ROW_RA + k) * 64 + lane] = d.ra[k];
+                hi[ROW_MIX * 64 + lane] = d.wmix;
+            }
+            split_post(sync + 0, (uint32_t)j + 1u, lane);
+            pslot = (pslot + 1 == K) ? 0 : pslot + 1;
+        }
+        return;
+    }
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ integrator
+        float *const s_img = reinterpret_cast<float *>(smem + Lds::OFF_IMG) + pair * (Env::RESET_ROWS * 64);
+        unsigned char *const s_wlist = smem + Lds::OFF_WLIST + pair * 64;
+        int step = (int)((p.ctr + base)[lane] & NIG_CTR_STEP_MASK);
+        float s[S], nx[S], integ[A], eprev[A];
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[lane];
+        // PID memory lives in the handle (baseline_agents.py:55-80): loaded here, stored at the end
+        const bool pid_mem = q.pid != nullptr && pol->kind == NIG_POLICY_PID;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            integ[j] = pid_mem ? (q.pid + base + (size_t)j * p.ld)[lane] : 0.0f;
+            eprev[j] = pid_mem ? (q.pid + base + (size_t)(A + j) * p.ld)[lane] : 0.0f;
+        }
+        PolicyRegs<Env> pr;                        // the feedback law's coefficients in registers (see PolicyRegs)
+        pr.load(*pol);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_setprio(3);
+        int slot = 0;
+        uint32_t seen = 0u;
+        for (int i = 0; i < n; ++i) {
+            if (seen < (uint32_t)i + 1u) seen = split_wait(sync + 0, (uint32_t)i + 1u);
+            const float *hi = s_hi + slot * Lds::HI_SLOT;
+            double nz[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) nz[k] = (double)hi[k * 64 + lane];
+            PolicyDraws<A> d;
+            if (any_sigma) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.z[k] = hi[(ROW_Z + k) * 64 + lane];
+            }
+            if (any_half) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.h[k] = hi[(ROW_H + k) * 64 + lane];
+            }
+            if (mix) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.ra[k] = hi[(ROW_RA + k) * 64 + lane];
+                d.wmix = hi[ROW_MIX * 64 + lane];
+            }
+            float a[A];
+            policy_apply<Env>(&pr, s, d, integ, eprev, a);
+            float *ih = s_ih + slot * Lds::IH_SLOT;
+            v4f *row = reinterpret_cast<v4f *>(ih) + lane * (S / 4);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; row[k] = v; }
+#pragma unroll
+            for (int k = 0; k < A; ++k) ih[(2 * S + 1 + k) * 64 + lane] = a[k];          // the policy's action, before the env's clip
+            StepResult<Env> res;
+            step_core<Env>(s, a, nz, step, p.max_steps, p.dt32, p.dt, p.cmask, nx, res);  // the reward part is dead here
+            const bool done = res.terminated || res.truncated;
+            v4f *rown = reinterpret_cast<v4f *>(ih + S * 64) + lane * (S / 4);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) { v4f v = {nx[4 * k], nx[4 * k + 1], nx[4 * k + 2], nx[4 * k + 3]}; rown[k] = v; }
+            reinterpret_cast<uint32_t *>(ih + 2 * S * 64)[lane] = res.viol_bits;
+            split_post(sync + 1, (uint32_t)i + 1u, lane);
+            step = done ? 0 : step + 1;
+            const unsigned long long m = __ballot(done);
+            if (m != 0ull)
+                coop_reset<Env>(m, done, lane, s_img, s_wlist, p.env0 + (uint64_t)base, t_base + (uint32_t)i + 1u,
+                                p.seed_lo, p.seed_hi, s_probit, nx);
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[k] = nx[k];
+            slot = (slot + 1 == K) ? 0 : slot + 1;
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[lane] = s[k];
+        if (pid_mem) {
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                (q.pid + base + (size_t)j * p.ld)[lane] = integ[j];
+                (q.pid + base + (size_t)(A + j) * p.ld)[lane] = eprev[j];
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- recorder
+    uint32_t ctr = (p.ctr + base)[lane];
+    const bool tally = p.tally != nullptr;
+    double ret = tally ? (p.ep_ret + base)[lane] : 0.0;
+    LaneTally lt;
+    lt.clear();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int cslot = 0;
+    uint32_t seen = 0u;
+    for (int i = 0; i < n; ++i) {
+        if (seen < (uint32_t)i + 1u) seen = split_wait(sync + 1, (uint32_t)i + 1u);
+        const float *ih = s_ih + cslot * Lds::IH_SLOT;
+        float nx[S], a[A];
+        const v4f *rown = reinterpret_cast<const v4f *>(ih + S * 64) + lane * (S / 4);
+#pragma unroll
+        for (int k = 0; k < S / 4; ++k) { const v4f v = rown[k]; nx[4 * k] = v.x; nx[4 * k + 1] = v.y; nx[4 * k + 2] = v.z; nx[4 * k + 3] = v.w; }
+        const uint32_t vb = reinterpret_cast<const uint32_t *>(ih + 2 * S * 64)[lane];
+#pragma unroll
+        for (int k = 0; k < A; ++k) a[k] = ih[(2 * S + 1 + k) * 64 + lane];
+        v4f tr[S / 4];
+        if (q.obs_out) {                           // the wave's 64 observation rows in lane-contiguous order
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) tr[k] = reinterpret_cast<const v4f *>(ih)[lane + 64u * k];
+        }
+        split_post(sync + 2, (uint32_t)i + 1u, lane);
+        const uint32_t orow = (uint32_t)i * q.out_stride;
+        if (q.obs_out) {
+            v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)i * q.obs_step_stride + (size_t)base * S);
+#pragma unroll
+            for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, tr[k]);
+        }
+        if (q.act_out) {
+            float *ao = q.act_out + (size_t)i * q.act_step_stride + base;
+#pragma unroll
+            for (int j = 0; j < A; ++j) stream_store(ao + j * q.ld_act_out + lane, a[j]);
+        }
+        clip_action<Env, float>(a);                // what step_core did to it on the integrator (base.py:167)
+        const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+        StepResult<Env> res;
+        post_core<Env, float>(nx, a, vb, step_pre, p.max_steps, res);
+        const int step = step_pre + 1;
+        const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+        const bool done = res.terminated || res.truncated;
+        const uint32_t fl = pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u);
+        ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+        if (tally) {
+            if constexpr (Env::RET_F32) ret = (double)((float)ret + res.reward);
+            else ret = ret + (double)res.reward;
+        }
+        if (p.reward) stream_store(p.reward + base + orow + lane, (float)res.reward);
+        if (p.flags) stream_store(p.flags + base + orow + lane, fl);
+        if (done) {
+            lt.life += (long long)viol_ep;
+            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            ctr = 0u;
+        }
+        cslot = (cslot + 1 == K) ? 0 : cslot + 1;
+    }
+    (p.ctr + base)[lane] = ctr;
+    if (lt.life != 0) (p.life_viol + base)[lane] += lt.life;
+    if (tally) {
+        (p.ep_ret + base)[lane] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + base + lane, p.ld, p.n_en);
+    }
+}
+
+}  // namespace nig

@@ -112,6 +112,47 @@ def test_split_form_handle_variants(ni, kw):
     _same(a, b)
 
 
+def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
+    """Closed-loop rollouts (nig_rollout_policy) through one handle; returns every observable as CPU tensors."""
+    ni.tune(split_blocks=256 if split else 0)
+    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
+    env.set_policy(policy)
+    env.reset()
+    got = []
+    for T in chunks:
+        rew = fl = obs = act = None
+        if stream != "none":
+            rew = torch.full((T, env.ld), float("nan"), dtype=torch.float32, device=env.device)
+            fl = torch.zeros(T, env.ld, dtype=torch.int32, device=env.device)
+        if stream == "transitions":
+            obs = torch.full((T, B, env.state_dim), float("nan"), dtype=torch.float32, device=env.device)
+            act = torch.full((T, env.action_dim, env.ld), float("nan"), dtype=torch.float32, device=env.device)
+        env.rollout_policy(T, rew, fl, obs, act)
+        torch.cuda.synchronize()
+        got += [t.cpu() if t is obs else t[..., :B].cpu() for t in (rew, fl, obs, act) if t is not None]
+    got += [env.state_soa.cpu(), env.ctr.cpu(), env.life_viol.cpu(), env.ep_return.cpu(), env.tally.cpu()]
+    env.close()
+    return got
+
+
+@pytest.mark.parametrize("stream", ["none", "rows", "transitions"])
+@pytest.mark.parametrize("which", ["expert", "medium", "mixed", "random", "pid", "mpc", "constant", "uniform"])
+def test_split_policy_form_equals_one_wave_form(ni, which, stream):
+    """nig_rollout_policy in the three-wave form (csrc/nig_split_policy.hpp) against rollout_policy_kernel: every
+    kind of on-device policy (feedback law with exploration normals, epsilon-mix with a uniform action, PID with
+    memory carried across launches, constant, uniform random), with and without the transition stream."""
+    S, A = 12, 3
+    if which in ("expert", "medium", "mixed", "random"):
+        policy = ni.behaviour_policy(NAME, which)
+    else:
+        policy = {"pid": lambda: ni.pid_agent(S, A), "mpc": lambda: ni.mpc_agent(S, A), "constant": lambda: ni.constant_agent(S, A),
+                  "uniform": lambda: ni.random_agent(S, A)}[which]()
+    kw = dict(policy=policy, B=1024, chunks=[9, 1, 14], stream=stream, max_steps=11)
+    a = _run_policy(ni, True, **kw)
+    b = _run_policy(ni, False, **kw)
+    _same(a, b)
+
+
 def test_split_form_at_the_headline_batch(ni):
     """65 536 lanes x 250 steps, default 500-step episodes, row-major trajectory: the benchmark's launch."""
     kw = dict(B=65536, chunks=[250], outputs="aos", R=16, max_steps=None)
