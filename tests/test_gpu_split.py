@@ -153,6 +153,16 @@ def test_split_policy_form_equals_one_wave_form(ni, which, stream):
     _same(a, b)
 
 
+@pytest.mark.parametrize("max_steps", [1, 2, 3])
+def test_split_form_resets_every_step(ni, max_steps):
+    """Episodes of one to three steps: every lane (or half / a third of them) is renewed by the cooperative reset
+    in every step, the integrator's heaviest path, while producer and recorder keep running ahead / behind."""
+    kw = dict(B=2048, chunks=[40], outputs="aos", R=4, max_steps=max_steps)
+    a, _ = _run(ni, True, **kw)
+    b, _ = _run(ni, False, **kw)
+    _same(a, b)
+
+
 def test_split_form_at_the_headline_batch(ni):
     """65 536 lanes x 250 steps, default 500-step episodes, row-major trajectory: the benchmark's launch."""
     kw = dict(B=65536, chunks=[250], outputs="aos", R=16, max_steps=None)
