@@ -171,8 +171,9 @@ def rollout_kernel_name(wl):
     """The kernel nig_rollout launches for this workload (csrc/nig_kernels.hpp launch_rollout_form): ChemicalReactor
     batches of whole 256-lane blocks, up to nig_tune(NIG_TUNE_SPLIT_BLOCKS) of them, run in the three-wave form."""
     out = {"none": 0, "min": 1, "full": 3}[wl.outputs]
-    blocks = wl.B // 256
-    if wl.key == "cr" and wl.B % 256 == 0 and 0 < blocks <= wl.ni.tune()["split_blocks"]:
+    blocks, per_round = wl.B // 256, wl.ni.tune()["split_blocks"]
+    last = blocks % per_round if per_round else 0
+    if wl.key == "cr" and wl.B % 256 == 0 and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 

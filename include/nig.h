@@ -130,11 +130,13 @@ const char *nig_last_error(void);
 
 /* Process-wide tuning knobs.  Results never depend on them: every kernel form a knob selects between is
  * bit-identical (tests/test_gpu_split.py).  No counterpart upstream.
- *   NIG_TUNE_SPLIT_BLOCKS   largest batch, in 256-lane blocks, that nig_rollout runs in the three-wave form
+ *   NIG_TUNE_SPLIT_BLOCKS   256-lane blocks per ROUND of the three-wave form of nig_rollout / nig_rollout_policy
  *                           (csrc/nig_split.hpp: producer / integrator / recorder wave per 64 ChemicalReactor
- *                           lanes); default = one block per compute unit of the device
- *                           the first handle is created on (256 on an MI355X), 0 = never.  The environment
- *                           variable NIG_SPLIT_BLOCKS sets the initial value.
+ *                           lanes, one block resident per compute unit); default = the compute units of the device
+ *                           the first handle is created on (256 on an MI355X), 0 = never use that form.  nig_rollout
+ *                           uses it for batches of at most one round and for larger ones whose last round is at
+ *                           least 3/4 full, nig_rollout_policy for at most one round.  The environment variable
+ *                           NIG_SPLIT_BLOCKS sets the initial value.
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
 enum { NIG_TUNE_SPLIT_BLOCKS = 0 };
 int nig_tune(int32_t key, int64_t value);

@@ -1557,10 +1557,15 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
     const unsigned n_full = q.s.B / BLOCK;
     RolloutArgs r = q;
     if constexpr (PAIRED && split_rollout<Env>::value) {
-        // up to one 256-lane block per CU the batch leaves a single wave on every SIMD: integrator + helper wave
-        // per 64 lanes (nig_split.hpp).  Larger batches fill the SIMDs with lanes and keep the one-wave form.
+        // Up to one 256-lane block per CU the batch leaves a single wave on every SIMD: producer / integrator /
+        // recorder wave per 64 lanes instead (nig_split.hpp; one block per CU is resident).  Larger batches run that
+        // form in ROUNDS of one block per CU, which beats the one-wave form (lanes filling the SIMDs) by 4-12 % when
+        // the rounds come out even -- measured at 2, 3, 4, 8 and 16 rounds, profiles/r02/rounds_probe.txt -- and loses
+        // when the last round is mostly empty (1.5 rounds: -8 %): used when the last round is at least 3/4 full.
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        if (plain && n_full > 0 && n_full <= g_split_blocks) {
+        const unsigned last_round = g_split_blocks ? n_full % g_split_blocks : 0u;
+        const bool even_rounds = g_split_blocks != 0 && (n_full <= g_split_blocks || last_round == 0 || 4u * last_round >= 3u * g_split_blocks);
+        if (plain && n_full > 0 && even_rounds) {
             r.block0 = 0;
             launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
             if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }

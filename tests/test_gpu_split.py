@@ -171,6 +171,14 @@ def test_split_form_at_the_headline_batch(ni):
     _same(a, b)
 
 
+def test_split_form_in_two_rounds(ni):
+    """131 072 lanes = two rounds of one block per CU (the form is used for batches whose rounds come out even)."""
+    kw = dict(B=131072, chunks=[31], outputs="aos", R=8, max_steps=20)
+    a, _ = _run(ni, True, **kw)
+    b, _ = _run(ni, False, **kw)
+    _same(a, b)
+
+
 def test_tune_knob_roundtrip(ni):
     assert ni.tune(split_blocks=17)["split_blocks"] == 17
     assert ni.tune()["split_blocks"] == 17
