@@ -12,6 +12,8 @@ bash profiles/run_pmc.sh r02_cr65536_rollout_full --steps 20 --warmup 5 --no-pow
 bash profiles/run_pmc.sh r02_pg262144_rollout_full --env pg --batch 262144 --steps 10 --warmup 2 > gpurun_out/pmc_pg.log 2>&1 && cp gpurun_out/pmc_r02_pg262144_rollout_full/traffic_r02_pg262144_rollout_full.json profiles/r02/r02_pg262144_rollout_full_pmc_traffic.json
 bash profiles/run_sq.sh r02_pg262144 --env pg --batch 262144 --steps 10 --warmup 2 --no-powergrid > profiles/r02/pg262144_rollout_full_sq.txt 2>&1
 bash profiles/run_sq.sh r02_cr65536 --steps 20 --warmup 5 --no-powergrid > profiles/r02/cr65536_rollout_full_sq.txt 2>&1
+# closed-loop policy rollouts (three-wave form at 65 536 lanes) under the tracer
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02_policy -o r02_policy -- python3 profiles/bench_policy.py --steps 100 > gpurun_out/prof_r02_policy.json 2> gpurun_out/prof_policy.log && cp $(find gpurun_out/prof_r02_policy -name "*kernel_stats.csv" | head -1) profiles/r02/policy_cr65536_kernel_stats.csv
 # ONE graph-replay PMC pass (the abort of round 1 left no log; library built beforehand this time), stderr kept
 timeout -k 10 200 bash profiles/run_pmc.sh r02_cr65536_graph_step --mode graph --steps 8 --warmup 2 > gpurun_out/pmc_graph.log 2>&1; echo "graph pmc rc=$?" | tee -a gpurun_out/pmc_graph.log
 cp gpurun_out/pmc_r02_cr65536_graph_step/traffic_r02_cr65536_graph_step.json profiles/r02/r02_cr65536_graph_step_pmc_traffic.json 2>/dev/null
