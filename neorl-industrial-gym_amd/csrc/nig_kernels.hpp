@@ -498,13 +498,23 @@ template <class Env, int OUT>
 struct RolloutLds {
     static constexpr int NWAVE = BLOCK / 64;
     static constexpr int OFF_PROBIT = 0;
-    static constexpr int OFF_IMG = OFF_PROBIT + 768 * 16;                                          // float [NWAVE][RESET_ROWS][64]
-    static constexpr int OFF_WLIST = OFF_IMG + (Env::COOP_RESET ? NWAVE * Env::RESET_ROWS * 64 * 4 : 0);   // uchar [BLOCK]
+    // Per-wave scratch: the cooperative reset's image [RESET_ROWS][64] and, for the row-major trajectory, the transpose
+    // image [16 S] float4 -- ONE region for both (a wave uses them at different points of its step, and its DS
+    // operations execute in order).  Separate regions put RobotAssembly's row-major kernel at 66 KB per block, two
+    // blocks per CU instead of the three its registers allow.
+    static constexpr int IMG_BYTES = Env::COOP_RESET ? Env::RESET_ROWS * 64 * 4 : 0;
+    static constexpr int TR_BYTES = OUT == 3 ? 16 * Env::S * 16 : 0;
+    static constexpr bool SHARE_SCRATCH = Env::COOP_RESET && OUT == 3;
+    static constexpr int WAVE_SCRATCH = SHARE_SCRATCH ? (IMG_BYTES > TR_BYTES ? IMG_BYTES : TR_BYTES) : IMG_BYTES;   // bytes per wave at OFF_IMG
+    static constexpr int OFF_IMG = OFF_PROBIT + 768 * 16;                                          // [NWAVE][WAVE_SCRATCH]
+    static constexpr int OFF_WLIST = OFF_IMG + NWAVE * WAVE_SCRATCH;                                // uchar [BLOCK]
     static constexpr int OFF_INIT = OFF_WLIST + (Env::COOP_RESET ? BLOCK : 0);                      // float [S][BLOCK]
     static constexpr int OFF_LIST = OFF_INIT + (Env::COMPACT_RESET ? Env::S * BLOCK * 4 : 0);       // ushort [BLOCK]
     static constexpr int OFF_CNT = OFF_LIST + (Env::COMPACT_RESET ? BLOCK * 2 : 0);                 // int [NWAVE]
-    static constexpr int OFF_TR = OFF_CNT + (Env::COMPACT_RESET ? 16 : 0);                          // v4f [NWAVE][16 S]
-    static constexpr int BYTES = OFF_TR + (OUT == 3 ? NWAVE * 16 * Env::S * 16 : 0);
+    static constexpr int OFF_TR = SHARE_SCRATCH ? OFF_IMG : OFF_CNT + (Env::COMPACT_RESET ? 16 : 0);   // v4f [NWAVE][TR_STRIDE]
+    static constexpr int TR_STRIDE = (SHARE_SCRATCH ? WAVE_SCRATCH : TR_BYTES) / 16;                // float4 per wave
+    static constexpr int IMG_STRIDE = WAVE_SCRATCH / 4;                                             // floats per wave
+    static constexpr int BYTES = SHARE_SCRATCH ? OFF_CNT + (Env::COMPACT_RESET ? 16 : 0) : OFF_TR + NWAVE * TR_BYTES;
 };
 
 template <class Env, int OUT, bool PAIRED, bool FULL>
@@ -644,11 +654,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
         }
         if constexpr (OUT == 3) {                  // stage this lane's row; read back transposed below
             if constexpr (S % 4 == 0) {
-                v4f *tr = s_tr + (tid >> 6) * (16 * S) + (tid & 63u) * (S / 4);
+                v4f *tr = s_tr + (tid >> 6) * Lds::TR_STRIDE + (tid & 63u) * (S / 4);
 #pragma unroll
                 for (int k = 0; k < S / 4; ++k) { v4f v = {n[4 * k], n[4 * k + 1], n[4 * k + 2], n[4 * k + 3]}; tr[k] = v; }
             } else {
-                float *tr = reinterpret_cast<float *>(s_tr + (tid >> 6) * (16 * S)) + (tid & 63u) * S;
+                float *tr = reinterpret_cast<float *>(s_tr + (tid >> 6) * Lds::TR_STRIDE) + (tid & 63u) * S;
 #pragma unroll
                 for (int k = 0; k < S; ++k) tr[k] = n[k];
             }
@@ -672,7 +682,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
             // contiguous KiB each.  (DS operations of one wave execute in order: the reads see the writes
             // issued above without a wait in between.)
             const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
-            const v4f *tr = s_tr + (tid >> 6) * (16 * S);
+            const v4f *tr = s_tr + (tid >> 6) * Lds::TR_STRIDE;
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
             constexpr int NV = (16 * S + 63) / 64;  // float4 pieces per lane: the wave's block is 64*S floats = 16*S float4
             v4f v[NV];
@@ -721,7 +731,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
             const unsigned long long m = __ballot(done && autoreset);
             if (m != 0ull) {                       // wave-uniform
                 const unsigned lane = tid & 63u, wave = tid >> 6;
-                coop_reset<Env>(m, done, lane, s_img + wave * (Env::RESET_ROWS * 64), s_wlist + wave * 64,
+                coop_reset<Env>(m, done, lane, s_img + wave * Lds::IMG_STRIDE, s_wlist + wave * 64,
                                 p.env0 + (uint64_t)(base + (tid & ~63u)), t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi,
                                 s_probit, n);
                 if (done) ctr = 0u;
