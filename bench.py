@@ -173,7 +173,7 @@ def rollout_kernel_name(wl):
     out = {"none": 0, "min": 1, "full": 3}[wl.outputs]
     blocks, per_round = wl.B // 256, wl.ni.tune()["split_blocks"]
     last = blocks % per_round if per_round else 0
-    if wl.key == "cr" and wl.B % 256 == 0 and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):
+    if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):   # (+ a one-wave launch for a ragged last block)
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 

@@ -251,3 +251,31 @@ def test_bench_traffic_lookup_is_per_env_step_and_keyed_by_plan_length():
     pg, _ = bench.measured_traffic("pg", 262144, "rollout", "full", 250)
     assert pg is not None and 160.0 < pg < 190.0
     assert bench.alg_bytes_rollout(12, 3, "full") == 68 and bench.alg_bytes_per_step(32, 8) == 304
+
+
+def test_bench_names_the_kernel_the_library_launches():
+    """bench.py's roofline.kernel follows the host rule of csrc/nig_kernels.hpp launch_rollout_form: the three-wave
+    form for ChemicalReactor batches of whole 256-lane blocks that are at most one round (one block per CU) or whose
+    last round is at least 3/4 full; everything else the one-wave rollout_kernel."""
+    import types
+
+    import bench
+    import neorl_industrial_gym_amd as ni
+    before = ni.tune()["split_blocks"]
+    try:
+        ni.tune(split_blocks=256)
+        def name(key, B, outputs="full"):
+            return bench.rollout_kernel_name(types.SimpleNamespace(key=key, B=B, outputs=outputs, ni=ni))
+        assert name("cr", 65536) == "split_rollout_kernel<ChemicalReactor,3,4>"
+        assert name("cr", 65536, "none") == "split_rollout_kernel<ChemicalReactor,0,4>"
+        assert name("cr", 1024, "min") == "split_rollout_kernel<ChemicalReactor,1,4>"
+        assert name("cr", 131072).startswith("split_") and name("cr", 1048576).startswith("split_")   # even rounds
+        assert name("cr", 65536 + 49152 + 256).startswith("split_")                                   # last round 193 / 256 blocks
+        assert name("cr", 98304).startswith("rollout_kernel<")                                        # 1.5 rounds
+        assert name("cr", 65536 + 100).startswith("split_")          # whole blocks in this form, the ragged last block in a one-wave launch
+        assert name("cr", 200).startswith("rollout_kernel<")          # no whole block at all
+        assert name("pg", 262144) == "rollout_kernel<PowerGrid,3>"
+        ni.tune(split_blocks=0)
+        assert name("cr", 65536).startswith("rollout_kernel<")
+    finally:
+        ni.tune(split_blocks=before)
