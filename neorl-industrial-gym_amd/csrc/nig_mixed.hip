@@ -6,7 +6,10 @@
 // launch), then runs that env's rollout body -- the same device function the per-env kernels wrap, hence the
 // same results bit for bit.  One launch instead of one per segment: no per-kernel tails (a 150 k-lane PowerGrid
 // segment alone fills the chip 1.14 times: its second round ran at 14 % occupancy), no launch fan-out.
-// The price of one kernel for all envs: every block runs under the register allocation of the hungriest body.
+// The price of one kernel for all envs: every block runs under ONE register allocation.  It is set for three waves
+// per SIMD (168 registers): PowerGrid's body, which wants ~185 and runs at two waves per SIMD as a kernel of its
+// own, spills ~70 dwords here, but the other six bodies and the chip as a whole gain more from the third wave than
+// PowerGrid loses (1 048 576 lanes, README set: 4.31 -> 3.75 ms per 250 steps; LDS, 45 KB per block, allows three).
 #include "nig_kernels.hpp"
 
 namespace nig {
@@ -24,7 +27,7 @@ struct MixedLds {
 
 // OUT: 0 = no per-step outputs, 1 = reward + flag word rows (the padded [n_steps][ld] matrices).
 template <int OUT>
-__global__ void __launch_bounds__(BLOCK, 2) mixed_rollout_kernel(const MixedArgs m)
+__global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs m)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[MixedLds<OUT>::BYTES];
     // Segment of this block (block-uniform).  The table is walked with COMPILE-TIME indices and scalar selects: a
