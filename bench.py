@@ -2,7 +2,11 @@
 """bench.py -- env-steps/sec of the IndustrialEnv.step() hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE).
+  N > 1: one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torch.distributed.run).  Started WITHOUT a launcher,
+  `bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run ... bench.py <same args>`,
+  before this process has imported torch or touched the GPU), relays rank 0's JSON line, checks that the line
+  says n_gpus == N with N ranks in the tally exchange, and exits with the children's status.  A world that
+  differs from --gpus is an error (non-zero exit), never a silent 1-GPU run.
 
 One bench "step" = ONE PASS of the hot path over the batch = one fused launch that runs
 --plan-steps (default 250) consecutive IndustrialEnv.step() calls of every lane (the shape of
@@ -105,11 +109,27 @@ class Workload:
                 self.traj = (torch.empty(rows, B, self.S, dtype=torch.float32, device=device).expand(P, B, self.S) if traj_layout == "aos"   # row-major [T,B,S]
                              else torch.empty(rows, self.S, env.ld, dtype=torch.float32, device=device).expand(P, self.S, env.ld))
         self.plan = env.make_plan(P, self.ring, env.reward, env.flags) if mode == "graph" else None
+        self.rings, self._turn = [self.ring], 0
+
+    def use_big_ring(self, min_bytes):
+        """Action rings whose union exceeds `min_bytes`: a launch reads slots 0..P-1 of ITS ring only (step k reads slot
+        k mod R), so consecutive launches cycle through several P-slot rings -- the bytes re-read between two uses of
+        a slot exceed the 256 MB Infinity Cache (the default 64-slot ring, 50 MB for the headline, sits inside it)."""
+        slot_bytes = self.A * self.env.ld * 4
+        n = max(2, -(-int(min_bytes) // (self.P * slot_bytes)))
+        big = self.torch.empty(n, self.P, self.A, self.env.ld, dtype=self.torch.float32, device=self.ring.device)
+        for j in range(n):
+            for s_ in range(self.P):
+                self.env.fill_actions(5000 + j * self.P + s_, big[j, s_])
+        self.rings = [big[j] for j in range(n)]
+        return n * self.P * slot_bytes
 
     def launch(self):
         """One bench step: P env.step of every lane."""
         if self.mode == "rollout":
-            self.env.rollout(self.P, self.ring, self.rew, self.fl, self.traj)
+            ring = self.rings[self._turn]
+            self._turn = (self._turn + 1) % len(self.rings)
+            self.env.rollout(self.P, ring, self.rew, self.fl, self.traj)
         elif self.mode == "graph":
             self.plan.launch()
         else:
@@ -144,27 +164,68 @@ def settle(torch, wl, seconds):
 def timed(torch, dist, world, comm_dev, wl, K, W, settle_s=0.0):
     """[settle_s of untimed load,] W untimed + exactly K timed launches, bracketed by barrier + synchronize on both
     sides; HIP events on the launch stream around the same region.  Returns (wall s, device ms): max over ranks."""
-    settle(torch, wl, settle_s)
+    gpu = torch.cuda.is_available()          # False only in the CPU control-flow rehearsal (NIG_BENCH_REHEARSE=cpu)
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
+    if gpu:
+        settle(torch, wl, settle_s)
     for _ in range(W):
         wl.launch()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    ev0 = ev1 = None
+    if gpu:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
+    if gpu:
+        ev0.record()
+    for _ in range(K):
+        wl.launch()
+    if gpu:
+        ev1.record()
+    sync()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    tm = torch.tensor([wall, ev0.elapsed_time(ev1) if gpu else wall * 1e3], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    return float(tm[0].item()), float(tm[1].item())
+
+
+def timed_events(torch, wl, K):
+    """K launches between two HIP events on the launch stream; no barrier, no warm-up.  Returns us per launch."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(K):
         wl.launch()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    tm = torch.tensor([wall, ev0.elapsed_time(ev1)], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    return float(tm[0].item()), float(tm[1].item())
+    return ev0.elapsed_time(ev1) * 1e3 / K
+
+
+def honest_brackets(torch, wl, K, roof, settle_s, idle_gap=1.0):
+    """What the sustained headline figure does not show, measured on the same workload object:
+    * write_only_frac   -- the output bytes alone (4S+8 per env-step; action reads can be served by the Infinity Cache,
+                           the trajectory stores cannot) / launch time / peak: the floor of the HBM-side fraction;
+    * cold_first_launches -- the same K launches re-timed right after `idle_gap` seconds of idle, no settle, no warm-up;
+    * ring_gt_mall      -- sustained, with action rings of > 2 x 256 MB cycled launch by launch, so every action
+                           read comes from HBM."""
+    env_steps = wl.B * wl.P
+    out = {"write_only_frac": (4 * wl.S + 8) * env_steps / (roof["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+           if wl.outputs == "full" else None}
+    torch.cuda.synchronize()
+    time.sleep(idle_gap)
+    us = timed_events(torch, wl, K)
+    out["cold_first_launches"] = {"launches": K, "idle_gap_s": idle_gap, "launch_us": us,
+                                  "frac": roof["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    ring_bytes = wl.use_big_ring(2 * 256 * 2**20 + 1)
+    settle(torch, wl, settle_s)
+    us = timed_events(torch, wl, K)
+    out["ring_gt_mall"] = {"ring_bytes": ring_bytes, "rings": len(wl.rings), "launch_us": us,
+                           "frac": roof["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    return out
 
 
 def rollout_kernel_name(wl):
@@ -175,6 +236,10 @@ def rollout_kernel_name(wl):
     last = blocks % per_round if per_round else 0
     if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):   # (+ a one-wave launch for a ragged last block)
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
+    # PowerGrid: whole 512-lane blocks of a batch of at least nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS) of them run the
+    # LDS-resident wide form (csrc/nig_pg_lds.hpp); the rest of the batch (< 512 lanes) the register-resident kernel
+    if wl.key == "pg" and wl.B // 512 >= max(1, wl.ni.tune()["wide_min_blocks"]):
+        return "rollout_wide_kernel<PowerGrid,%d,512>" % out
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 
 
@@ -200,9 +265,13 @@ def roofline_of(wl, K, dev_ms):
 def gathered_tally(torch, dist, world, comm_dev, wl):
     """The path's one exchange: all-gather of every rank's partial tally + fixed-order combine.
     Self-check: every rank contributed and the combined counts are the sums of the per-rank ones."""
+    return gathered_partial(world, comm_dev, wl.ni, wl.env.reduce_tally())
+
+
+def gathered_partial(world, comm_dev, ni, partial):
     from neorl_industrial_gym_amd.parallel import all_gather_partials, combine_partials
-    L = wl.ni._lib
-    parts = all_gather_partials(wl.env.reduce_tally().to(comm_dev)).cpu()
+    L = ni._lib
+    parts = all_gather_partials(partial.to(comm_dev)).cpu()
     total = combine_partials(parts).numpy()
     per_rank_eps = [int(x) for x in parts[:, L.T_EPISODES].tolist()]
     ok = (parts.shape[0] == world and all(e > 0 for e in per_rank_eps)
@@ -280,7 +349,73 @@ def cpu_baseline(key, B, seconds, seed=0x5EED):
                                                "to the GPU box, so this is a stated constant, not a live measurement"}}
 
 
-def main():
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and verify it.  This process has imported neither
+    torch nor the package and has made no HIP call (a process that has touched the GPU must not start another program
+    in its place); the library is built here first if stale, so the ranks do not race to compile it."""
+    import importlib.util
+    import socket
+    import subprocess
+    spec = importlib.util.spec_from_file_location("_nig_build", os.path.join(ROOT, "neorl-industrial-gym_amd", "_build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.ensure()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                        # only rank 0 prints the result line; anything else is passed through
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: the {n}-rank child job exited with status {rc}")
+    if line is None:
+        raise SystemExit("bench.py: the child job printed no result line")
+    rec = json.loads(line)
+    if rec.get("n_gpus") != n or rec.get("ranks") != n or len(rec.get("episodes_per_rank", [])) != n:
+        raise SystemExit(f"bench.py: asked for {n} ranks, the line reports n_gpus={rec.get('n_gpus')} ranks={rec.get('ranks')}")
+    print(line)
+    return 0
+
+
+class RehearsalWorkload:
+    """NIG_BENCH_REHEARSE=cpu (tests only, a box without a GPU): stands in for the device workload so that the N-rank
+    CONTROL FLOW -- spawn, rendezvous, barriers, max-over-ranks timing, the tally all-gather + fixed-order combine and
+    its self-check, the result line -- runs over gloo.  It computes nothing: `launch` is a no-op and the partial tally
+    is a made-up, rank-dependent vector; the line it produces carries value null and says so."""
+
+    def __init__(self, ni, torch, rank):
+        self.ni, self.torch, self.rank = ni, torch, rank
+        self.env = self
+
+    def launch(self):
+        pass
+
+    def reduce_tally(self):
+        L = self.ni._lib
+        p = self.torch.zeros(L.T_ROWS, dtype=self.torch.float64)
+        p[L.T_EPISODES] = 100 + self.rank
+        p[L.T_VIOL] = 7 * (self.rank + 1)
+        p[L.T_CRIT] = self.rank
+        p[L.T_RET_SUM] = -50.0 * (100 + self.rank)
+        p[L.T_RET_MIN], p[L.T_RET_MAX] = -60.0 - self.rank, -40.0 + self.rank
+        return p
+
+    def close(self):
+        pass
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed launches (one launch = --plan-steps env.step of every lane)")
@@ -301,15 +436,36 @@ def main():
     ap.add_argument("--mixed-set", default="readme", choices=["readme", "survey"],
                     help="--env mixed: the README's seven envs, or SURVEY 8(d).4's seven (the three reference envs + the two "
                          "Advanced candidates + two README-only plants)")
+    ap.add_argument("--mixed-outputs", default="full", choices=["full", "min"],
+                    help="--env mixed / the mixed sub-record: full = per-step observation rows [T][S_max][ld] + reward + flags; min = reward + flags")
     ap.add_argument("--mixed-launch", default="fused", choices=["fused", "streams"],
                     help="--env mixed: one kernel launch over all segments (nig_create_mixed) or one launch per segment on its own stream")
     ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
     ap.add_argument("--no-powergrid", action="store_true", help="skip the secondary PowerGrid (BASELINE configs[2]/[4]) measurement")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the secondary mixed-batch (BASELINE configs[3]) measurement")
+    ap.add_argument("--no-brackets", action="store_true",
+                    help="skip the headline's brackets (cold first launches, action rings larger than the Infinity Cache)")
     ap.add_argument("--calibrate", action="store_true", help="also run known-size dword copies (PMC calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the all-core CPU baseline sample")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher (nothing below runs here; no torch, no HIP call so far)
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus} ...` "
+                         f"(it launches its own ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
 
     import torch
     import torch.distributed as dist
@@ -317,25 +473,28 @@ def main():
     # the package (and with it libnig.so, built here if stale) is loaded BEFORE anything touches the GPU
     import neorl_industrial_gym_amd as ni
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # NIG_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend (a 1-GPU box cannot host two
-    # RCCL ranks); used only to rehearse the N>1 control flow, never for a reported number.
-    rehearse = os.environ.get("NIG_BENCH_REHEARSE") == "1"
-    dev_index = 0 if rehearse else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    # NIG_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend (a 1-GPU box cannot host two RCCL ranks);
+    # NIG_BENCH_REHEARSE=cpu: no GPU at all, control flow only (RehearsalWorkload).  Neither ever gives a reported number.
+    mode_r = os.environ.get("NIG_BENCH_REHEARSE", "")
+    rehearse = mode_r in ("1", "cpu")
+    if mode_r == "cpu":
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        dev_index = 0 if rehearse else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     comm_dev = torch.device("cpu") if rehearse else device
+    if mode_r == "cpu":
+        return rehearse_cpu(args, ni, torch, dist, comm_dev, world, rank)
 
     if args.env == "mixed":
         return bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank)
@@ -383,11 +542,19 @@ def main():
         w3.close()
         del w3
 
+    # ---- secondary: all 7 envs mixed-batch, 1 048 576 lanes per GPU (BASELINE configs[3]), ONE fused launch
+    mixed = None
+    if key == "cr" and args.mode == "rollout" and not args.no_mixed:
+        mixed = measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, 1048576, max(2, min(K, 8)), 2,
+                              args.settle, per_env_rates=False)
+
     # ---- headline: workload resident in HBM before the timed region
     wl = Workload(ni, torch, key, B, device, rank, args.mode, P, args.ring, args.outputs, args.traj)
     wall, dev_ms = timed(torch, dist, world, comm_dev, wl, K, W, args.settle)
     roof = roofline_of(wl, K, dev_ms)
     total, tally_check = gathered_tally(torch, dist, world, comm_dev, wl)
+    if args.mode == "rollout" and not args.no_brackets:
+        roof.update(honest_brackets(torch, wl, K, roof, args.settle))
 
     if args.calibrate:   # known-size dword-per-lane copies for the PMC byte calibration (profiles/)
         cal = torch.empty(wl.S, wl.env.ld, dtype=torch.float32, device=device)
@@ -404,7 +571,8 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node) + safety-violation-count parity, ChemicalReactor-v0"
                       if key == "cr" else f"env-steps/sec (whole node), {ENVS[key]}",
-            "value": K * P * B * world / wall, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": K * P * B * world / wall, "unit": "env-steps/s", "n_gpus": world, "ranks": tally_check["ranks"],
+            "episodes_per_rank": tally_check["episodes_per_rank"], "steps": K, "warmup": W,
             "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ENVS[key]}, batch={B} parallel envs per GPU; one bench step = "
@@ -425,6 +593,8 @@ def main():
             out["step_api"] = step_api
         if powergrid is not None:
             out["powergrid"] = powergrid
+        if mixed is not None:
+            out["mixed"] = mixed
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
@@ -432,6 +602,26 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def rehearse_cpu(args, ni, torch, dist, comm_dev, world, rank):
+    """Control flow of an N-rank run on a box without a GPU (tests/test_host_logic.py).  No measurement: value null."""
+    wl = RehearsalWorkload(ni, torch, rank)
+    K, W = max(1, args.steps), max(0, args.warmup)
+    wall, _ = timed(torch, dist, world, comm_dev, wl, K, W)
+    total, check = gathered_tally(torch, dist, world, comm_dev, wl)
+    if rank == 0:
+        L = ni._lib
+        print(json.dumps({"metric": "env-steps/sec (whole node) + safety-violation-count parity, ChemicalReactor-v0",
+                          "value": None, "unit": "env-steps/s", "n_gpus": world, "ranks": check["ranks"],
+                          "episodes_per_rank": check["episodes_per_rank"], "steps": K, "warmup": W,
+                          "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "none", "rehearsal": "cpu control flow only: no device workload ran",
+                          "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
+                                    "critical": int(total[L.T_CRIT])}, "tally_check": check}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 MIXED7 = [("ChemicalReactor-v0", 12, 3, "reference"), ("RobotAssembly-v0", 24, 7, "reference"),
@@ -447,70 +637,90 @@ MIXED7_SURVEY = [("ChemicalReactor-v0", 12, 3, "reference"), ("PowerGrid-v0", 32
                  ("HVACControl-v0", 18, 5, "build-specified"), ("WaterTreatment-v0", 15, 4, "build-specified")]
 
 
-def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
-    """BASELINE config 4: the README's seven environments (README.md:24-32) in ONE padded SoA batch of
-    --batch lanes (default 1 048 576), contiguous 256-aligned segments of equal size.  --mixed-launch
-    fused: ONE kernel launch over all segments (block -> env table, heaviest envs first);
-    streams: one rollout kernel per segment on its own stream (round-1 form).  Three of the seven
-    exist upstream and are parity-checked against the reference; four are README-only there and run
-    build-specified plants (flagged per env).  Reports total and per-env throughput; the HBM figure is
-    the lane-weighted fused-rollout byte count with reward+flags outputs."""
-    B = args.batch or 1048576
+def measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, B, K, W, settle_s, per_env_rates=True):
+    """BASELINE config 4: the README's seven environments (README.md:24-32) in ONE padded SoA batch of B lanes per
+    GPU, contiguous 256-aligned segments of equal size.  --mixed-launch fused: ONE kernel launch over all segments
+    (block -> env table, heaviest envs first); streams: one rollout kernel per segment on its own stream (round-1
+    form).  Three of the seven exist upstream and are parity-checked against the reference; four are README-only
+    there and run build-specified plants (flagged per env).  --mixed-outputs full: every step's observation rows go to
+    a padded [T][S_max][ld] trajectory (what get_dataset stores); min: reward + flag word only.  The byte model is the
+    lane-weighted fused-rollout figure of the outputs requested."""
     per = (B // 7) // 256 * 256
     envset = MIXED7 if args.mixed_set == "readme" else MIXED7_SURVEY
     counts = [(name, per if i else B - 6 * per) for i, (name, _, _, _) in enumerate(envset)]
     dims = {name: (S, A) for name, S, A, _ in envset}
     origin = {name: o for name, _, _, o in envset}
     fused = args.mixed_launch == "fused"
+    full = args.mixed_outputs == "full"
     mix = ni.MixedBatchedEnv(counts, device=device, seed=0x5EED, autoreset=True, tally=True, env_index0=rank * B,
                              fused=fused)
-    P, K, W = max(1, args.plan_steps), max(1, args.steps), max(0, args.warmup)
+    P = max(1, args.plan_steps)
     R = min(args.ring, 16)
     ring = torch.zeros(R, mix.A_max, mix.ld, dtype=torch.float32, device=device)
     for s in range(R):
         mix.fill_actions(1000 + s, ring[s])
     rew = torch.empty(P, mix.ld, dtype=torch.float32, device=device)
     fl = torch.empty(P, mix.ld, dtype=torch.int32, device=device)
+    obs = torch.empty(P, mix.S_max, mix.ld, dtype=torch.float32, device=device) if full else None
     mix.reset()
 
     class _W:
         def launch(self):
-            mix.rollout(P, ring, rew, fl)
-    wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W, args.settle)
+            mix.rollout(P, ring, rew, fl, obs)
+    wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W, settle_s)
     # per-env rate measured separately on its own segment size (same per-env kernels, stand-alone launch)
     per_env = {}
     for (name, n), seg, o in zip(counts, mix.envs, mix.offsets):
-        reps = max(1, K // 4)
-        torch.cuda.synchronize(); c0 = time.perf_counter()
-        for _ in range(reps):
-            seg.rollout(P, ring[:, :seg.action_dim, o:o + n], rew[:, o:o + n], fl[:, o:o + n])
-        torch.cuda.synchronize()
         per_env[name] = {"lanes": n, "state_dim": dims[name][0], "action_dim": dims[name][1],
-                         "env_steps_per_s": reps * P * n / (time.perf_counter() - c0),
                          "dynamics": origin[name], "reference_parity": origin[name] == "reference"}
+        if per_env_rates:
+            reps = max(1, K // 4)
+            torch.cuda.synchronize(); c0 = time.perf_counter()
+            for _ in range(reps):
+                seg.rollout(P, ring[:, :seg.action_dim, o:o + n], rew[:, o:o + n], fl[:, o:o + n],
+                            None if obs is None else obs[:, :seg.state_dim, o:o + n])
+            torch.cuda.synchronize()
+            per_env[name]["env_steps_per_s"] = reps * P * n / (time.perf_counter() - c0)
+    from neorl_industrial_gym_amd.parallel import combine_partials
+    _, tally_check = gathered_partial(world, comm_dev, ni, combine_partials(torch.stack(mix.reduce_tally())))
+    bytes_launch = sum((4 * v["action_dim"] + 8 + (4 * v["state_dim"] if full else 0)) * v["lanes"] for v in per_env.values()) * P
+    launch_us = dev_ms * 1e3 / K
+    achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+    out_mode = 2 if full else 1
+    rec = {"value": K * P * B * world / wall, "unit": "env-steps/s", "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K,
+           "config": {"workload": f"mixed padded-SoA batch of {B} lanes per GPU (S_max={mix.S_max}, A_max={mix.A_max}): "
+                                  + ", ".join(f"{n} x {e}" for e, n in counts) + f"; one bench step = {P} env.step per lane, "
+                                  + ("ONE fused launch over all segments" if fused else "one launch per segment on 7 streams")
+                                  + (", outputs: observation rows [T][S_max][ld] + reward + flags" if full else ", reward+flags outputs"),
+                      "batch_per_gpu": B, "plan_steps": P, "env_steps_per_step": P * B * world, "segments": counts,
+                      "launch": args.mixed_launch, "outputs": args.mixed_outputs},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": ("mixed_rollout_kernel<%d>" % out_mode) if fused else "rollout_kernel<*,%d> x7 (concurrent streams)" % out_mode,
+                        "alg_bytes_per_launch": bytes_launch, "launch_us": launch_us,
+                        "bytes_model": "fused-rollout figure: action read + requested per-step outputs per env-step, lane-weighted"},
+           "tally_check": tally_check, "per_env": per_env}
+    mix.close()
+    return rec
+
+
+def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
+    """--env mixed: BASELINE config 4 as the headline of its own line."""
+    B = args.batch or 1048576
+    K, W = max(1, args.steps), max(0, args.warmup)
+    rec = measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, B, K, W, args.settle)
     if rank == 0:
-        bytes_launch = sum((4 * v["action_dim"] + 8) * v["lanes"] for v in per_env.values()) * P
-        launch_us = dev_ms * 1e3 / K
-        achieved = bytes_launch / (launch_us * 1e-6) / 1e9
         print(json.dumps({
-            "metric": "env-steps/sec (whole node), all 7 envs mixed-batch", "value": K * P * B * world / wall,
-            "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mixed padded-SoA batch of {B} lanes per GPU (S_max={mix.S_max}, A_max={mix.A_max}): "
-                                   + ", ".join(f"{n} x {e}" for e, n in counts) + f"; one bench step = {P} env.step per lane, "
-                                   + ("ONE fused launch over all segments" if fused else "one launch per segment on 7 streams")
-                                   + ", reward+flags outputs", "batch_per_gpu": B, "plan_steps": P,
-                       "env_steps_per_step": P * B * world, "segments": counts, "launch": args.mixed_launch},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mixed_rollout_kernel<1>" if fused else "rollout_kernel<*,1> x7 (concurrent streams)",
-                         "alg_bytes_per_launch": bytes_launch, "launch_us": launch_us,
-                         "bytes_model": "fused-rollout figure: action read + reward + flag word per env-step, lane-weighted"},
-            "per_env": per_env}))
+            "metric": "env-steps/sec (whole node), all 7 envs mixed-batch", "value": rec["value"],
+            "unit": "env-steps/s", "n_gpus": world, "ranks": rec["tally_check"]["ranks"],
+            "episodes_per_rank": rec["tally_check"]["episodes_per_rank"], "steps": K, "warmup": W,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"],
+            "per_env": rec["per_env"]}))
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -137,8 +137,12 @@ const char *nig_last_error(void);
  *                           uses it for batches of at most one round and for larger ones whose last round is at
  *                           least 3/4 full, nig_rollout_policy for at most one round.  The environment variable
  *                           NIG_SPLIT_BLOCKS sets the initial value.
+ *   NIG_TUNE_WIDE_MIN_BLOCKS  smallest batch, in 512-lane blocks, that nig_rollout runs in the WIDE form (csrc/nig_kernels.hpp
+ *                           rollout_wide_kernel: PowerGrid / RobotAssembly, 512-thread blocks at four waves per SIMD,
+ *                           handles on which no lane can be frozen); default 256 (one wide block per compute unit),
+ *                           a huge value = never.  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
-enum { NIG_TUNE_SPLIT_BLOCKS = 0 };
+enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1 };
 int nig_tune(int32_t key, int64_t value);
 int64_t nig_tune_get(int32_t key);
 

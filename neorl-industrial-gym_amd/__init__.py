@@ -22,14 +22,18 @@ from .policies import (DevicePolicy, MLPPolicy, behaviour_policy, constant_agent
                        pid_agent, random_agent)
 from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
 
-def tune(split_blocks=None):
+def tune(split_blocks=None, wide_min_blocks=None):
     """Process-wide kernel-selection knobs of libnig (include/nig.h nig_tune); results never depend on them.
     split_blocks: largest batch, in 256-lane blocks, that rollout() runs in the three-wave form (0 = never).
+    wide_min_blocks: smallest batch, in 512-lane blocks, that rollout() runs in the wide form (PowerGrid / RobotAssembly).
     Returns the current settings."""
     L = _lib.lib()
     if split_blocks is not None:
         _lib.check(L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, int(split_blocks)))
-    return {"split_blocks": int(L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS))}
+    if wide_min_blocks is not None:
+        _lib.check(L.nig_tune(_lib.TUNE_WIDE_MIN_BLOCKS, int(wide_min_blocks)))
+    return {"split_blocks": int(L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS)),
+            "wide_min_blocks": int(L.nig_tune_get(_lib.TUNE_WIDE_MIN_BLOCKS))}
 
 
 __version__ = "0.1.0"

@@ -26,6 +26,7 @@ MAX_EPISODE_STEPS = 21845
  T_SHUTDOWN, T_SUCCESS, T_SATISFIED, T_CONSTRAINTS, T_ROWS) = range(14)
 
 TUNE_SPLIT_BLOCKS = 0
+TUNE_WIDE_MIN_BLOCKS = 1
 
 SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",

@@ -245,6 +245,12 @@ unsigned g_split_blocks = [] {
     if (e) g_split_explicit = true;
     return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
 }();
+// Smallest batch, in wide (512-lane) blocks, that runs the wide rollout form (envs with WIDE_ROLLOUT_BLOCK): default
+// one wide block per compute unit -- below that 256-lane blocks put the batch on more CUs.  NIG_WIDE_MIN_BLOCKS / nig_tune.
+unsigned g_wide_min_blocks = [] {
+    const char *e = getenv("NIG_WIDE_MIN_BLOCKS");
+    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
+}();
 static void split_default_from_device(int device)
 {
     static bool done = false;
@@ -262,12 +268,17 @@ const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)
 {
-    if (key != NIG_TUNE_SPLIT_BLOCKS || value < 0 || value > 0x7fffffffLL) return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
+    if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < 0 || value > 0x7fffffffLL)
+        return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
+    if (key == NIG_TUNE_WIDE_MIN_BLOCKS) { nig::g_wide_min_blocks = (unsigned)value; return NIG_OK; }
     nig::g_split_blocks = (unsigned)value;
     nig::g_split_explicit = true;
     return NIG_OK;
 }
-int64_t nig_tune_get(int32_t key) { return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::g_split_blocks : -1; }
+int64_t nig_tune_get(int32_t key)
+{
+    return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::g_split_blocks : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::g_wide_min_blocks : -1;
+}
 
 int nig_env_id(const char *name)
 {

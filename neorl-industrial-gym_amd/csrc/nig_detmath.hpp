@@ -205,10 +205,20 @@ struct u32x4 { uint32_t x, y, z, w; };
 // (Measured on gfx950: the wide multiply issues like an ordinary VALU instruction -- replacing five of
 // PowerGrid's six blocks per step with an add/xor/rotate stream of equal instruction count changed
 // nothing beyond the count.)
+// Written as "a * b + z" with z an SGPR pair the compiler cannot see through (it holds 0): instruction selection
+// then folds multiply and add into v_mad_u64_u32 ITSELF.  Rounds 1-2 had the instruction as inline asm, and hipcc's
+// hazard recognizer, blind to what an asm statement is, put an s_nop behind almost every one of them: 70 of
+// PowerGrid's ~1 250 issue slots per step.  The asm below has no inputs and no side effects: identical copies are
+// merged and hoisted, one s_mov_b64 per kernel.
+__device__ __forceinline__ uint64_t opaque_zero64()
+{
+    uint64_t z;
+    asm("s_mov_b64 %0, 0" : "=s"(z));
+    return z;
+}
 __device__ __forceinline__ void mulhilo32(uint32_t m, uint32_t x, uint32_t &hi, uint32_t &lo)
 {
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "s"(m), "v"(x) : "vcc");
+    const uint64_t r = (uint64_t)m * (uint64_t)x + opaque_zero64();
     lo = (uint32_t)r;
     hi = (uint32_t)(r >> 32);
 }

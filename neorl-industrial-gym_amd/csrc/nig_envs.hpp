@@ -272,6 +272,8 @@ struct PowerGrid {
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     static constexpr int STEP_WAVES = 2, STEP_BLOCK = 512;   // big batches: two 512-thread blocks per CU = 4 waves per SIMD (128 VGPRs), LDS 2 x 76 KiB
     static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
+    // Big auto-reset batches run the LDS-resident form (nig_pg_lds.hpp): 512-thread blocks, four waves per SIMD.
+    static constexpr int WIDE_ROLLOUT_BLOCK = 512, WIDE_ROLLOUT_WAVES = 2;
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }
@@ -340,6 +342,12 @@ struct PowerGrid {
     __device__ static void reset_item(const RngKey &k, uint32_t blk, float *img, unsigned owner)
     {
         float *col = img + owner;
+        reset_item_to(k, blk, [col](uint32_t row, float v) { col[row * 64u] = v; });
+    }
+    // the same work item with the destination left to the caller: put(state row, initial value)
+    template <class Put>
+    __device__ static void reset_item_to(const RngKey &k, uint32_t blk, Put &&put)
+    {
         const bool uni = blk >= 6u;
         const u32x4 x = k.block(STREAM_RESET + (uni ? 10u + blk : blk));     // uniforms: STREAM_RESET + 16 + (blk - 6)
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -353,15 +361,15 @@ struct PowerGrid {
                 const double off = blk < 2u ? 1.0 : (blk < 4u ? (hi ? base_load(4 + q) : base_load(q)) : 0.0);
                 const double d = 0.0 + sd * (double)probit_normal(w[q], k.tab);
                 const float v = (float)(off + d);      // flows: 0.0 + d == d (d is never -0.0)
-                if (q < 3 || blk != 5u) col[(row0 + (uint32_t)q) * 64u] = v;   // z[23] does not exist
+                if (q < 3 || blk != 5u) put(row0 + (uint32_t)q, v);   // z[23] does not exist
             }
-            if (blk == 0u) col[0] = 0.0f;
+            if (blk == 0u) put(0u, 0.0f);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double nn = -0.2 + (0.2 - -0.2) * u01(w[q]);           // :104 uniform: low + (high-low)*u
                 const double b = hi ? base_load(4 + q) : base_load(q);
-                col[(17u + 4u * (blk - 6u) + (uint32_t)q) * 64u] = (float)(b * (1.0 + nn));   // :105
+                put(17u + 4u * (blk - 6u) + (uint32_t)q, (float)(b * (1.0 + nn)));   // :105
             }
         }
     }
@@ -474,32 +482,59 @@ struct PowerGrid {
         return reward(n, none) + (-5.0 * sum8(a2));                      // :173-175 (the float32 form adds -5.0f * 0 = -0.0)
     }
 
-    // _compute_reward :155-177 (float32 terms, fp64 economic term, fp64 total)
-    __device__ static double reward(const float (&n)[S], const float (&a)[A])
+    // _compute_reward :155-177 (float32 terms, fp64 economic term, fp64 total), in the four terms the reference adds up
+    // (the LDS-resident rollout, nig_pg_lds.hpp, evaluates them where their inputs are at hand)
+    __device__ static float reward_freq(float f) { return -100.0f * (f * f); }          // :162 (scalar ** 2: within 1 ulp of powf)
+    __device__ static float reward_volt(const float (&v)[8])                             // :165-166
     {
-        const float fr = -100.0f * (n[0] * n[0]);                        // :162 (scalar ** 2: within 1 ulp of powf)
-        float d2[8], a2[8];
-        double cg[8];
+        float d2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float d = fabsf(n[1 + i] - 1.0f);                      // :165
+            const float d = fabsf(v[i] - 1.0f);
             d2[i] = d * d;
-            cg[i] = gen_cost(i) * (double)n[9 + i];                      // :169 int64 * float32 -> float64
-            a2[i] = a[i] * a[i];
         }
-        const float vr = -50.0f * sum8(d2);                              // :166
-        const double er = (-sum8(cg)) / 1000.0;                          // :170
-        const float ap = -5.0f * sum8(a2);                               // :173
-        return ((double)(fr + vr) + er) + (double)ap;                    // :175
+        return -50.0f * sum8(d2);
+    }
+    __device__ static double reward_econ(const float (&g)[8])                            // :169-170 int64 * float32 -> float64
+    {
+        double cg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cg[i] = gen_cost(i) * (double)g[i];
+        return (-sum8(cg)) / 1000.0;
+    }
+    __device__ static float reward_act(const float (&a)[A])                              // :173
+    {
+        float a2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a2[i] = a[i] * a[i];
+        return -5.0f * sum8(a2);
+    }
+    __device__ static double reward_total(float fr, float vr, double er, float ap)       // :175
+    {
+        return ((double)(fr + vr) + er) + (double)ap;
+    }
+    __device__ static double reward(const float (&n)[S], const float (&a)[A])
+    {
+        float v[8], g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = n[1 + i]; g[i] = n[9 + i]; }
+        return reward_total(reward_freq(n[0]), reward_volt(v), reward_econ(g), reward_act(a));
     }
 
     // _is_done :179-192
+    __device__ static bool done_fv(float f, const float (&v)[8])
+    {
+        bool bad = fabsf(f) > 1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bad = bad || (v[i] < 0.9f) || (v[i] > 1.1f);
+        return bad;
+    }
     __device__ static bool done(const float (&n)[S])
     {
-        bool bad = fabsf(n[0]) > 1.0f;
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bad = bad || (n[1 + i] < 0.9f) || (n[1 + i] > 1.1f);
-        return bad;
+        for (int i = 0; i < 8; ++i) v[i] = n[1 + i];
+        return done_fv(n[0], v);
     }
 };
 
@@ -650,7 +685,6 @@ struct RobotAssembly {
     }
     __device__ static double reward(const float (&n)[S], const double (&a)[A])
     {
-        const float none[A] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         double ap = 0.0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) ap = ap + a[i] * a[i];               // :211 float64, sequential

@@ -91,18 +91,25 @@ __device__ __forceinline__ void clip_action(AT (&a)[Env::A])
 // the reward's type at the end of the reference's arithmetic: float64 as soon as the action is float64
 template <class Env, class AT> using reward_of = std::conditional_t<std::is_same<AT, double>::value, double, typename Env::reward_t>;
 
+template <class Env, class R>
+__device__ __forceinline__ void post_finish(R r, bool term, uint32_t vb, int step_pre, int max_steps, StepResult<Env, R> &out);
+
 template <class Env, class AT>
 __device__ __forceinline__ void post_core(const float (&n)[Env::S], const AT (&a)[Env::A], uint32_t vb,
                                           int step_pre, int max_steps, StepResult<Env, reward_of<Env, AT>> &out)
 {
-    using R = reward_of<Env, AT>;
-    R r = Env::reward(n, a);                      // base.py:176
+    post_finish<Env, reward_of<Env, AT>>(Env::reward(n, a) /* base.py:176 */, Env::done(n) /* base.py:190 */, vb, step_pre, max_steps, out);
+}
+
+// the env-independent rest of IndustrialEnv.step once the reward and the env's own termination test are known
+template <class Env, class R>
+__device__ __forceinline__ void post_finish(R r, bool term, uint32_t vb, int step_pre, int max_steps, StepResult<Env, R> &out)
+{
 #pragma unroll
     for (int k = 0; k < 3; ++k)                   // base.py:179-183, constraint order
         r = (vb & (1u << k)) ? (R)(r + (R)Env::penalty(k)) : r;
     const int nviol = __popc(vb);
     const int ncrit = __popc(vb & Env::CRIT_MASK);
-    bool term = Env::done(n);                     // base.py:190
     const bool trunc = (step_pre + 1) >= max_steps;   // base.py:191
     if (ncrit > 0) { term = true; r = r - (R)1000; }  // base.py:195-198
     out.reward = r; out.viol_bits = vb; out.nviol = nviol; out.ncrit = ncrit;
@@ -268,13 +275,18 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
                                            const float4 *tab, float (&n)[Env::S])
 {
     constexpr int LOG2 = Env::RESET_ITEMS_LOG2;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
     if (mine) lst[rank] = (unsigned char)lane;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const int total = __popcll(m) << LOG2;
     for (int i = (int)lane; i < total; i += 64) {
-        const unsigned owner = lst[i >> LOG2];
-        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)i & ((1u << LOG2) - 1u), img, owner);
+        // The item index is laundered: in the first pass it equals the lane index, a loop invariant of the ROLLOUT loop
+        // around this call, and hipcc then hoists every per-block constant select of reset_item (standard deviations,
+        // offsets, row numbers: ~30 registers for PowerGrid) out of that loop and keeps them alive across the whole step.
+        int ii = i;
+        asm volatile("" : "+v"(ii));
+        const unsigned owner = lst[ii >> LOG2];
+        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)ii & ((1u << LOG2) - 1u), img, owner);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (mine) Env::reset_readback(img, lane, n);
@@ -494,8 +506,9 @@ struct RolloutArgs {
 // LDS of one rollout block, carved from ONE buffer the kernel declares (the per-env kernels size it for their own
 // env and output mode, the mixed-batch kernel for the largest of its envs): generator table, then the env's
 // reset scratch, then the per-wave transpose image of the row-major trajectory.
-template <class Env, int OUT>
+template <class Env, int OUT, int BLK = 256>
 struct RolloutLds {
+    static constexpr int BLOCK = BLK;            // shadows the file-wide constant
     static constexpr int NWAVE = BLOCK / 64;
     static constexpr int OFF_PROBIT = 0;
     // Per-wave scratch: the cooperative reset's image [RESET_ROWS][64] and, for the row-major trajectory, the transpose
@@ -517,9 +530,18 @@ struct RolloutLds {
     static constexpr int BYTES = SHARE_SCRATCH ? OFF_CNT + (Env::COMPACT_RESET ? 16 : 0) : OFF_TR + NWAVE * TR_BYTES;
 };
 
-template <class Env, int OUT, bool PAIRED, bool FULL>
+// NOFREEZE (only with FULL): the host has checked that no lane of the handle can be frozen (auto-reset handle, no lane
+// holding NIG_CTR_DONE), so the pre-step state is dead once the dynamics have read it -- with the run-time flag the
+// "discard the speculative step" path keeps all S pre-step values alive next to the S new ones through the whole step
+// (PowerGrid: 32 of the registers that capped it at two waves per SIMD).
+// BLK: threads per block (256; 512 for the wide form of envs with a big per-wave LDS scratch: the 12 KiB generator
+// table is then shared by eight waves and two blocks = four waves per SIMD fit a CU).
+template <class Env, int OUT, bool PAIRED, bool FULL, bool NOFREEZE = false, int BLK = 256>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
 {
+    static_assert(!NOFREEZE || FULL, "NOFREEZE is a property of whole-block launches");
+    static_assert(BLK == 256 || (Env::COOP_RESET && !Env::COMPACT_RESET), "wide blocks: no block barrier inside the loop");
+    constexpr int BLOCK = BLK;                   // shadows the file-wide constant
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     // Envs whose episodes are short (PowerGrid ~6 steps, RobotAssembly: most waves see a reset
@@ -537,7 +559,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     constexpr bool COOP = Env::COOP_RESET;
     static_assert(!(COMPACT && COOP), "one reset scheme per env");
     constexpr int NWAVE = BLOCK / 64;
-    using Lds = RolloutLds<Env, OUT>;
+    using Lds = RolloutLds<Env, OUT, BLK>;
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
     float *const s_img = reinterpret_cast<float *>(smem + Lds::OFF_IMG);         // per wave: [RESET_ROWS][64] initial states, column = owner lane
     unsigned char *const s_wlist = smem + Lds::OFF_WLIST;                        // per wave: lanes that finished, in lane order
@@ -608,16 +630,16 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
     // block-uniform: lanes can be frozen (finished and waiting for reset -- also on an auto-reset handle whose lanes
     // were never reset, left out by reset(mask) or marked done by set_state: base.py:159-160 -- or out of range)
-    const bool may_freeze = !autoreset || (p.hflags & HF_MAY_HOLD_DONE) != 0 || (!FULL && base + BLOCK > p.B);
+    const bool may_freeze = NOFREEZE ? false : (!autoreset || (p.hflags & HF_MAY_HOLD_DONE) != 0 || (!FULL && base + BLOCK > p.B));
 
     auto one_step = [&](auto pos_tag, float (&abuf)[A], nz_t (&nz)[KSN], const int it) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
         const bool frozen = may_freeze && (ctr & NIG_CTR_DONE) != 0;   // no auto-reset: base.py:159-160
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
-        if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
+        if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
@@ -746,7 +768,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
         } else if (autoreset) {                    // block-uniform
             const unsigned wave = tid >> 6, lane = tid & 63u;
             const unsigned long long m = __ballot(done);
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
             if (lane == 0) s_cnt[wave] = __popcll(m);
             if (done) s_list[wave * 64 + rank] = (unsigned short)tid;
             __syncthreads();
@@ -834,11 +856,46 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
     rollout_body<Env, OUT, PAIRED, FULL>(q, (blockIdx.x + q.block0) * BLOCK, smem);
 }
 
+// The wide form (envs that declare WIDE_ROLLOUT_BLOCK): whole blocks of BLK lanes of a handle on which no lane can be
+// frozen.  q.block0 counts 256-lane blocks.
+template <class E, class = void> struct wide_rollout : std::integral_constant<int, 0> {};
+template <class E> struct wide_rollout<E, std::void_t<decltype(E::WIDE_ROLLOUT_BLOCK)>> : std::integral_constant<int, E::WIDE_ROLLOUT_BLOCK> {};
+
+}  // namespace nig
+#include "nig_pg_lds.hpp"
+namespace nig {
+template <class Env, int OUT, int BLK>
+struct wide_body {                                // default: the register-resident body without freeze handling
+    static constexpr int LDS_BYTES = RolloutLds<Env, OUT, BLK>::BYTES;
+    __device__ static __forceinline__ void run(const RolloutArgs &q, uint32_t base, unsigned char *smem)
+    {
+        rollout_body<Env, OUT, false, true, true, BLK>(q, base, smem);
+    }
+};
+template <int OUT, int BLK>
+struct wide_body<PowerGrid, OUT, BLK> {           // PowerGrid: state staged in LDS (nig_pg_lds.hpp)
+    static constexpr int LDS_BYTES = PgLds<BLK>::BYTES;
+    __device__ static __forceinline__ void run(const RolloutArgs &q, uint32_t base, unsigned char *smem)
+    {
+        pg_lds_rollout_body<OUT, BLK>(q, base, smem);
+    }
+};
+
+template <class Env, int OUT, int BLK>
+__global__ void __launch_bounds__(BLK, (BLK / 256) * Env::WIDE_ROLLOUT_WAVES) rollout_wide_kernel(const RolloutArgs q)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wide_body<Env, OUT, BLK>::LDS_BYTES];
+    wide_body<Env, OUT, BLK>::run(q, q.block0 * 256u + blockIdx.x * BLK, smem);
+}
+
 }  // namespace nig
 #include "nig_split.hpp"
 namespace nig {
 // Largest batch (in 256-lane blocks) the three-wave forms are used for (nig_tune(NIG_TUNE_SPLIT_BLOCKS); nig_api.hip).
 extern unsigned g_split_blocks;
+// Smallest batch (in wide blocks) the wide rollout form is used for (nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS); nig_api.hip):
+// below it the 256-lane blocks spread a small batch over more CUs.
+extern unsigned g_wide_min_blocks;
 
 // Mixed-batch launch (nig_mixed.hip): per-segment rollout arguments + the block -> segment table, in launch order.
 constexpr int MIXED_MAX_SEG = NIG_MIXED_MAX_SEGMENTS;
@@ -1582,7 +1639,23 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
             return;
         }
     }
-    if (n_full > 0) { r.block0 = 0; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full, st); }
+    unsigned first = 0;                            // first 256-lane block the forms below still have to run
+    if constexpr (!PAIRED && wide_rollout<Env>::value != 0) {
+        constexpr int WB = wide_rollout<Env>::value;
+        const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+        const unsigned n_wide = q.s.B / WB;
+        if (plain && n_wide >= g_wide_min_blocks) {
+            r.block0 = 0;
+            switch (out_mode) {
+            case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+            case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+            case 2: hipLaunchKernelGGL((rollout_wide_kernel<Env, 2, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+            default: hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+            }
+            first = n_wide * (WB / BLOCK);
+        }
+    }
+    if (n_full > first) { r.block0 = first; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full - first, st); }
     if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
 }
 

@@ -1,0 +1,300 @@
+// nig_pg_lds.hpp -- PowerGrid-v0's fused rollout with the per-timestep state staged in LDS (included by nig_kernels.hpp).
+//
+// BASELINE.json configs 3 and 5 (262 144 PowerGrid lanes per GPU).  rollout_kernel<PowerGrid> keeps a lane's 32 state
+// values in registers and draws the step's 23 normals into 23 more; with the action prefetch ring and the episode
+// tally that is ~185 registers = TWO waves per SIMD, and the SQ counters of round 2 showed the price: 4.9 cycles per
+// vector instruction where the instruction mix allows ~3.5 (profiles/r02/pg262144_rollout_full_sq.txt), 22 % of the
+// wave cycles waiting.  Here the state lives in a wave-private LDS image between steps:
+//
+//   image: float4 [8 lanes-of-8][8 groups][8 lanes] per wave (8 KiB) -- float4 group g (state values 4g .. 4g+3) of lane
+//   l at float4 index (l >> 3) * 64 + g * 8 + (l & 7): eight consecutive lanes are 128 contiguous bytes, so a lane's
+//   own-group ds_read_b128 / ds_write_b128 is conflict-free and the group is an immediate offset (no address math);
+//
+// and a step streams through it: read the groups a phase needs, update, write back.  PowerGrid's step is made for
+// this -- V, load and line-flow rows are independent random walks (power_grid.py:136-144), each touched once; only
+// the frequency couples the generation and load sums (:127-133).  Never more than ~28 state values and four normals
+// are live, the kernel is compiled for 128 registers, and with 512-thread blocks (the 12 KiB generator table shared by
+// eight waves: 12 + 8 x 8 KiB per block) two blocks = FOUR waves per SIMD are resident.
+//   * The image is also the transposing image of the row-major trajectory: the wave's 64 x 32 block leaves as eight
+//     1 KiB whole-line streaming stores read straight from it (the register kernel wrote the state to LDS every
+//     step for that anyway -- as 128-byte-strided ds_write_b128: eight lanes on the same four banks, 8-way conflicts).
+//   * The cooperative reset writes the initial values into the finishing lanes' image rows and nothing reads them back.
+// Arithmetic: the same expressions in the same order on the same values as PowerGrid::violated / dynamics (float32
+// noise branch) / reward / done and post_core, the same generator keys and words as draw_step / draw_init --
+// bit-identical to rollout_kernel<PowerGrid> and to the oracle (tests/test_gpu_round3.py, tests/test_gpu_parity.py).
+// Whole 512-lane blocks of an auto-reset handle without frozen lanes only; the host keeps every other case on
+// rollout_kernel.
+#pragma once
+
+namespace nig {
+
+template <int BLK>
+struct PgLds {
+    static constexpr int NWAVE = BLK / 64;
+    static constexpr int OFF_PROBIT = 0;
+    static constexpr int OFF_IMG = 768 * 16;                     // float4 [NWAVE][512]
+    static constexpr int OFF_WLIST = OFF_IMG + NWAVE * 8192;     // uchar [NWAVE][64]
+    static constexpr int BYTES = OFF_WLIST + NWAVE * 64;
+};
+
+template <int OUT, int BLK>
+__device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
+{
+    using Env = PowerGrid;
+    constexpr int S = Env::S, A = Env::A;
+    using Lds = PgLds<BLK>;
+    float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
+    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLK) s_probit[i_] = NIG_PROBIT[i_];
+    __syncthreads();
+    const StepArgs &p = q.s;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    v4f *const img = reinterpret_cast<v4f *>(smem + Lds::OFF_IMG) + wave * 512;
+    v4f *const mine = img + (lane >> 3) * 64 + (lane & 7u);         // group g of this lane: mine[8 g]
+    float *const imgf = reinterpret_cast<float *>(img);
+    unsigned char *const wl = smem + Lds::OFF_WLIST + wave * 64;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;    // step k uses t_base + k + 1
+    const uint64_t gi = p.env0 + (uint64_t)(base + tid);
+    const uint64_t wave_gi0 = p.env0 + (uint64_t)(base + (tid & ~63u));
+    const bool tally = p.tally != nullptr;
+
+    uint32_t ctr = (p.ctr + base)[tid];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float *r = p.state + base + (4 * g) * p.ld_state;
+        v4f v = {r[tid], (r + p.ld_state)[tid], (r + 2 * p.ld_state)[tid], (r + 3 * p.ld_state)[tid]};
+        mine[8 * g] = v;
+    }
+    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    LaneTally lt;
+    lt.clear();
+
+    const float *ring = p.actions + base;
+    // ONE action register set: the action of step it + 1 is loaded into it as soon as step it has consumed its own
+    // (clip, generation update, the reward's action term: the first ~80 instructions of a step), i.e. a whole step
+    // (~1 200 instructions, four waves sharing the SIMD) before it is used.  The wait for it is in order with the stores
+    // issued before it -- those of step it - 1, long acknowledged by then.  (rollout_body keeps two to four sets: its
+    // envs' steps are shorter and run at one or two waves per SIMD.)
+    constexpr int DEPTH = 1;
+    float buf[DEPTH][A];
+    int slot = q.it0 % q.ring_len;
+    const float *act_next;
+    float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
+    uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
+    float *obs_row = nullptr;
+    if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S;
+    if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
+    const unsigned rd = (lane & 7u) * 8u + (lane >> 3);             // transposed read: image float4 64 j + rd = row-major float4 64 j + lane
+
+    auto one_step = [&](float (&abuf)[A], const int it) __attribute__((always_inline)) {
+        float a[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) a[k] = abuf[k];
+        clip_action<Env, float>(a);
+        const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
+        // ---- generation, load sum, frequency (state values 0, 9 .. 24) --------------------------------------------
+        float v[8], ngen7;                         // v: the pre-step voltages, updated in place below
+        float n0, fr, ap;
+        double er;
+        uint32_t vb;
+        {
+            const v4f g0 = mine[0], g1 = mine[8], g2 = mine[16], g3 = mine[24], g4 = mine[32], g5 = mine[40], g6 = mine[48];
+            float s[S];                            // pre-step values, as far as violated() and the dynamics read them
+            s[0] = g0.x;
+            s[1] = g0.y; s[2] = g0.z; s[3] = g0.w; s[4] = g1.x; s[5] = g1.y; s[6] = g1.z; s[7] = g1.w; s[8] = g2.x;
+            s[9] = g2.y; s[10] = g2.z; s[11] = g2.w; s[12] = g3.x; s[13] = g3.y; s[14] = g3.z; s[15] = g3.w; s[16] = g4.x;
+            s[17] = g4.y; s[18] = g4.z; s[19] = g4.w; s[20] = g5.x; s[21] = g5.y; s[22] = g5.z; s[23] = g5.w; s[24] = g6.x;
+#pragma unroll
+            for (int k = 25; k < S; ++k) s[k] = 0.0f;      // line flows: read by nothing before their own update
+            vb = Env::violated(s, a) & p.cmask;            // base.py:170 on the pre-state, clipped action
+            float ngen[8], load[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float g = s[9 + i] + a[i];                                   // power_grid.py:124 np.clip(gen + a, 0, 100)
+                g = (g < 0.0f) ? 0.0f : g;
+                g = (g > 100.0f) ? 100.0f : g;
+                ngen[i] = g;
+                load[i] = s[17 + i];
+                v[i] = s[1 + i];
+            }
+            const float imb = sum8(ngen) - sum8(load);                       // :127-129
+            const float fd = fdiv_c((-1.0f * s[0]) + imb, 5.0f);             // :132
+            n0 = s[0] + fd * p.dt32;                                         // :133
+            // the reward's terms that do not wait for the voltages (:162, :169-173): the action and all of the new
+            // generation but three values are dead from here on
+            fr = Env::reward_freq(n0);
+            er = Env::reward_econ(ngen);
+            ap = Env::reward_act(a);
+            v4f w3 = {ngen[3], ngen[4], ngen[5], ngen[6]};
+            mine[24] = w3;
+            if constexpr (OUT == 2) {
+                stream_store(obs_row + tid, n0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) stream_store(obs_row + (9 + k) * q.ld_obs_out + tid, ngen[k]);
+            }
+            ngen7 = ngen[7];
+            // refill this action register set (step it + DEPTH), issued before the step's stores: see rollout_body
+#pragma unroll
+            for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
+            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+            act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------
+            u32x4 x = key.block(STREAM_STEP);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ProbitFetch f[4];
+                f[0] = probit_fetch(x.x, s_probit); f[1] = probit_fetch(x.y, s_probit);
+                f[2] = probit_fetch(x.z, s_probit); f[3] = probit_fetch(x.w, s_probit);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[4 * j + c] = v[4 * j + c] + 0.005f * probit_eval(f[c]);   // :136-137
+                __builtin_amdgcn_sched_barrier(0);
+                // (here the next block's rounds come AFTER the cubics: with the frequency / reward terms still live, rounds
+                // running over four table reads in flight cost the six registers that pushed the episode tally into
+                // scratch -- and a scratch reload drains vmcnt, i.e. every streaming store of the step.  The other waves
+                // of the SIMD cover the table latency; the load / line-flow phase below does overlap.)
+                x = key.block(STREAM_STEP + (uint32_t)(j + 1));
+            }
+            {
+                v4f w0 = {n0, v[0], v[1], v[2]}, w1 = {v[3], v[4], v[5], v[6]}, w2 = {v[7], ngen[0], ngen[1], ngen[2]};
+                mine[0] = w0; mine[8] = w1; mine[16] = w2;
+            }
+            if constexpr (OUT == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) stream_store(obs_row + (1 + k) * q.ld_obs_out + tid, v[k]);
+            }
+            // ---- IndustrialEnv.step after the dynamics (base.py:176-198): reward, penalties, termination ----------
+            const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+            StepResult<Env> res;
+            post_finish<Env, double>(Env::reward_total(fr, Env::reward_volt(v), er, ap), Env::done_fv(n0, v), vb, step_pre, p.max_steps, res);
+            const int step = step_pre + 1;
+            const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+            const bool done = res.terminated || res.truncated;
+            ctr = done ? 0u : ((uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT));
+            if (tally) ret = ret + res.reward;
+            if constexpr (OUT >= 1) {
+                stream_store(rew_row + tid, (float)res.reward);
+                stream_store(fl_row + tid, pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u));
+                rew_row += q.out_stride; fl_row += q.out_stride;
+            }
+            if (done) {                            // (lt.viol doubles as the lifetime violation count: two registers less)
+                if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+                else lt.viol += (int)viol_ep;
+            }
+            // ---- loads: blocks 2 and 3 (z[8..15], sd 1.0), then line flows: blocks 4 and 5 (z[16..22], sd 2.0) ----
+            float l7 = 0.0f;
+#pragma unroll
+            for (int j = 2; j < 6; ++j) {
+                ProbitFetch f[4];
+                f[0] = probit_fetch(x.x, s_probit); f[1] = probit_fetch(x.y, s_probit); f[2] = probit_fetch(x.z, s_probit);
+                if (j < 5) f[3] = probit_fetch(x.w, s_probit);               // z[23] does not exist
+                if (j < 5) x = key.block(STREAM_STEP + (uint32_t)(j + 1));
+                asm volatile("" ::: "memory");                               // the groups are read again HERE, not kept from the top
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 2) {                      // load[0..3]: group 4 = {gen7, load0, load1, load2}, load3 = group 5 .x
+                    const v4f h4 = mine[32], h5 = mine[40];
+                    float l[4] = {h4.y + probit_eval(f[0]), h4.z + probit_eval(f[1]), h4.w + probit_eval(f[2]), h5.x + probit_eval(f[3])};   // :140
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];                                   // :141
+                    v4f w4 = {ngen7, l[0], l[1], l[2]};
+                    mine[32] = w4;
+                    l7 = l[3];                     // load3', parked until its group is complete
+                    if constexpr (OUT == 2) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stream_store(obs_row + (17 + c) * q.ld_obs_out + tid, l[c]);
+                    }
+                } else if (j == 3) {               // load[4..7]: group 5 = {load3 .. load6}, load7 = group 6 .x
+                    const v4f h5 = mine[40], h6 = mine[48];
+                    float l[4] = {h5.y + probit_eval(f[0]), h5.z + probit_eval(f[1]), h5.w + probit_eval(f[2]), h6.x + probit_eval(f[3])};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];
+                    v4f w5 = {l7, l[0], l[1], l[2]};
+                    mine[40] = w5;
+                    if constexpr (OUT == 2) {
+                        stream_store(obs_row + 20 * q.ld_obs_out + tid, l7);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stream_store(obs_row + (21 + c) * q.ld_obs_out + tid, l[c]);
+                    }
+                    l7 = l[3];                     // load7'
+                } else if (j == 4) {               // flows[0..3]: group 6 = {load7, flow0, flow1, flow2}, flow3 = group 7 .x
+                    const v4f h6 = mine[48], h7 = mine[56];
+                    const float fl[4] = {h6.y + 2.0f * probit_eval(f[0]), h6.z + 2.0f * probit_eval(f[1]),
+                                         h6.w + 2.0f * probit_eval(f[2]), h7.x + 2.0f * probit_eval(f[3])};          // :144
+                    v4f w6 = {l7, fl[0], fl[1], fl[2]};
+                    mine[48] = w6;
+                    if constexpr (OUT == 2) {
+                        stream_store(obs_row + 24 * q.ld_obs_out + tid, l7);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stream_store(obs_row + (25 + c) * q.ld_obs_out + tid, fl[c]);
+                    }
+                    l7 = fl[3];                    // flow3'
+                } else {                           // flows[4..6]: group 7 = {flow3 .. flow6}
+                    const v4f h7 = mine[56];
+                    const float fl[3] = {h7.y + 2.0f * probit_eval(f[0]), h7.z + 2.0f * probit_eval(f[1]), h7.w + 2.0f * probit_eval(f[2])};
+                    v4f w7 = {l7, fl[0], fl[1], fl[2]};
+                    mine[56] = w7;
+                    if constexpr (OUT == 2) {
+                        stream_store(obs_row + 28 * q.ld_obs_out + tid, l7);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stream_store(obs_row + (29 + c) * q.ld_obs_out + tid, fl[c]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (OUT == 3) {
+                // the image now holds the wave's 64 post-step rows: row-major float4 64 j + lane sits at 64 j + rd
+                v4f *oo = reinterpret_cast<v4f *>(obs_row);
+                v4f v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = img[64 * j + rd];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, v[j]);
+            }
+            if constexpr (OUT >= 2) obs_row += q.obs_step_stride;
+            // ---- IndustrialEnv.reset for the lanes that finished (base.py:133-155), wave-cooperative: work item =
+            // (finishing lane, generator block) -> four state values, written into that lane's image row
+            const unsigned long long m = __ballot(done);
+            if (m != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
+                if (done) wl[rank] = (unsigned char)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const int total = __popcll(m) << 3;
+                for (int i = (int)lane; i < total; i += 64) {
+                    int ii = i;
+                    asm volatile("" : "+v"(ii));   // not a loop invariant of the rollout loop: see coop_reset
+                    const unsigned owner = wl[ii >> 3];
+                    float *row = imgf + ((owner >> 3) * 64u + (owner & 7u)) * 4u;
+                    Env::reset_item_to(make_key(wave_gi0 + owner, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit),
+                                       (uint32_t)ii & 7u, [row](uint32_t k, float v) { row[(k >> 2) * 32u + (k & 3u)] = v; });
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+        const float *nx = ring + (size_t)slot * q.slot_stride;
+#pragma unroll
+        for (int k = 0; k < A; ++k) buf[j][k] = (nx + k * p.ld_act)[tid];
+        slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+    }
+    act_next = ring + (size_t)slot * q.slot_stride;
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // prologue loads drained here, not in the loop header (rollout_body)
+    int it = q.it0;
+    for (; it < q.n_steps; ++it) one_step(buf[0], it);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const v4f v = mine[8 * g];
+        float *r = p.state + base + (4 * g) * p.ld_state;
+        r[tid] = v.x; (r + p.ld_state)[tid] = v.y; (r + 2 * p.ld_state)[tid] = v.z; (r + 3 * p.ld_state)[tid] = v.w;
+    }
+    (p.ctr + base)[tid] = ctr;
+    if (lt.viol != 0) (p.life_viol + base)[tid] += (long long)lt.viol;    // base.py:183 total_violations of the finished episodes
+    if (tally) {
+        (p.ep_ret + base)[tid] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
+    }
+}
+
+}  // namespace nig

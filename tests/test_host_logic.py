@@ -274,8 +274,45 @@ def test_bench_names_the_kernel_the_library_launches():
         assert name("cr", 98304).startswith("rollout_kernel<")                                        # 1.5 rounds
         assert name("cr", 65536 + 100).startswith("split_")          # whole blocks in this form, the ragged last block in a one-wave launch
         assert name("cr", 200).startswith("rollout_kernel<")          # no whole block at all
-        assert name("pg", 262144) == "rollout_kernel<PowerGrid,3>"
-        ni.tune(split_blocks=0)
-        assert name("cr", 65536).startswith("rollout_kernel<")
+        assert name("pg", 262144) == "rollout_wide_kernel<PowerGrid,3,512>"      # >= 256 blocks of 512 lanes: the LDS-resident form
+        assert name("pg", 65536) == "rollout_kernel<PowerGrid,3>"               # 128 wide blocks: below the default threshold
+        assert name("ra", 262144) == "rollout_kernel<RobotAssembly,3>"
+        ni.tune(split_blocks=0, wide_min_blocks=1 << 30)
+        assert name("cr", 65536).startswith("rollout_kernel<") and name("pg", 262144) == "rollout_kernel<PowerGrid,3>"
     finally:
-        ni.tune(split_blocks=before)
+        ni.tune(split_blocks=before, wide_min_blocks=256)
+
+
+def _run_bench(args, env_extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_and_verifies_its_own_ranks():
+    """`bench.py --gpus 2` WITHOUT torchrun starts two ranks itself (gloo here: no GPU in this container, so the
+    device workload is replaced by a stand-in -- the launch, rendezvous, barriers, tally all-gather / combine /
+    self-check and the result line are the real code), and the line says n_gpus == 2 with two ranks in the exchange.
+    The same flow with the real workload on one GPU: tests/test_gpu_abi_round2.py::test_bench_two_ranks_on_one_gpu."""
+    p, rec = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"NIG_BENCH_REHEARSE": "cpu"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["tally_check"]["ranks"] == 2
+    assert rec["episodes_per_rank"] == [100, 101] and rec["tally"]["episodes"] == 201
+    assert rec["value"] is None and "rehearsal" in rec          # never mistaken for a measurement
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """--gpus N under a launcher that formed another world size: non-zero exit, message names the command."""
+    p, rec = _run_bench(["--gpus", "2"], {"NIG_BENCH_REHEARSE": "cpu", "WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode != 0 and rec is None and "torch.distributed.run" in p.stderr
+    p, rec = _run_bench(["--gpus", "1"], {"NIG_BENCH_REHEARSE": "cpu", "WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and rec is None
