@@ -173,7 +173,7 @@ int nig_destroy(nig_handle *h);
 int nig_get_layout(const nig_handle *h, nig_layout *out);
 void *nig_workspace(const nig_handle *h);
 
-/* RNG launch counter t ("nig-philox-v1"): nig_reset draws with the current
+/* RNG launch counter t ("nig-philox-v2"): nig_reset draws with the current
  * t, nig_step increments t first; every draw is a pure function of (seed, global lane index, t),
  * whatever the launch shape (ChemicalReactor's two step draws come from the Philox block with
  * counter word (t+1)/2: words 0-1 for odd t, 2-3 for even t).  Exposed so a caller can

@@ -1,4 +1,4 @@
-// nig_detmath.hpp -- device-side deterministic math + counter-based RNG ("nig-philox-v1").
+// nig_detmath.hpp -- device-side deterministic math + counter-based RNG ("nig-philox-v2").
 //
 // Everything here is built from IEEE-754 + - * / only (file is compiled with
 // -ffp-contract=off, correctly-rounded division/sqrt), so a host evaluation of the same
@@ -190,9 +190,14 @@ __device__ __forceinline__ void det_sincos(double x, double &s, double &c)
 }
 
 // ---------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011), counter = (env_lo, env_hi, t, stream+block),
-// key = (seed_lo, seed_hi).
+// Philox4x32-7 (Salmon et al. 2011), counter = (env_lo, env_hi, t, stream+block),
+// key = (seed_lo, seed_hi).  Seven rounds since "nig-philox-v2" (ten in v1): Philox4x32-7 is the variant the
+// Random123 authors report as the fewest rounds that pass the whole of BigCrush (ten is their safety-margin default),
+// Random123 ships known-answer vectors for it (tests/test_oracle_golden.py), and the generator is this build's
+// workload spec, not the reference's (which draws from NumPy's MT19937).  The kernels are bound by vector-instruction
+// issue and a round is four instructions: PowerGrid runs 6 blocks per step + 8 per reset.
 // ---------------------------------------------------------------------------------
+constexpr int PHILOX_ROUNDS = 7;
 constexpr uint32_t STREAM_STEP = 0u;
 constexpr uint32_t STREAM_RESET = 0x40000000u;
 constexpr uint32_t STREAM_ACTION = 0x80000000u;
@@ -223,11 +228,11 @@ __device__ __forceinline__ void mulhilo32(uint32_t m, uint32_t x, uint32_t &hi, 
     hi = (uint32_t)(r >> 32);
 }
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1)
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         uint32_t h0, l0, h1, l1;
         mulhilo32(0xD2511F53u, c0, h0, l0);
         mulhilo32(0xCD9E8D57u, c2, h1, l1);
@@ -246,7 +251,7 @@ struct RngKey {
     const float4 *tab;        // the probit table staged in LDS by the kernel
     __device__ __forceinline__ u32x4 block(uint32_t stream_block) const
     {
-        return philox4x32_10(env_lo, env_hi, t, stream_block, seed_lo, seed_hi);
+        return philox4x32(env_lo, env_hi, t, stream_block, seed_lo, seed_hi);
     }
 };
 
@@ -255,7 +260,7 @@ struct RngKey {
 // (0, 0.5); the piece is picked by the float32 exponent and top 5 mantissa bits of f = m + 0.5
 // (24 binades x 32 = 768 pieces, narrower towards the tail), the low 18 mantissa bits are the
 // position inside the piece.  Max |error| 4.8e-7 (the float32 grid at z ~ 5); |z| <= 5.42.
-// ~14 VALU + one 16-byte LDS read, against ~43 VALU per normal for a polynomial Box-Muller
+// ~13 VALU + one 16-byte LDS read, against ~43 VALU per normal for a polynomial Box-Muller
 // (log + sqrt + sincos) -- PowerGrid draws 23 normals per env-step.  The table is generated data
 // (gen_probit_table.py); the oracle compiles the same data and runs the same float32 sequence.
 __device__ const float4 NIG_PROBIT[768] = {
@@ -272,7 +277,7 @@ __device__ __forceinline__ ProbitFetch probit_fetch(uint32_t word, const float4 
     const float x = (float)__builtin_amdgcn_ubfe(word, 8, 23) + 0.5f;   // m + 1/2, exact (one bit-field extract)
     const uint32_t b = f32_bits(x);
     f.c = tab[__builtin_amdgcn_ubfe(b, 18, 13) - (126u << 5)];
-    f.t = (float)(b & 0x3FFFFu) * (1.0f / 262144.0f);        // exact
+    f.t = (float)(b & 0x3FFFFu);       // position in the piece as an integer: its 2^-18 is folded into the table's coefficients (bit-identical, tests/probit_scale_check.c)
     return f;
 }
 

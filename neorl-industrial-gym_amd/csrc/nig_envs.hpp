@@ -65,15 +65,17 @@ struct ChemicalReactor {
         s[6] = (float)(295.0 + n[6]);     s[7] = 0.0f; s[8] = 0.0f; s[9] = 0.0f;
         s[10] = (float)(60.0 + n[7]);     s[11] = 0.0f;
     }
-    // fast mode: draws in reference call order, loc + scale*z in fp64 (np.random.normal)
+    // fast mode: draws in reference call order; since "nig-philox-v2" the draw is the float32 product sd * z (as the
+    // step noise), widened to the double init() takes.  The means are float32-representable, so (float)(mean + draw) is
+    // the float32 sum mean + draw rounded once: reset_item below computes it with one v_add_f32.
     __device__ static void draw_init(const RngKey &k, double (&n)[KR])
     {
         float z[KR];
         gen_normals<KR>(k, STREAM_RESET, z);
-        n[0] = 0.0 + 2.0 * (double)z[0];      n[1] = 0.0 + 10000.0 * (double)z[1];
-        n[2] = 0.0 + 5.0 * (double)z[2];      n[3] = 0.0 + 3.0 * (double)z[3];
-        n[4] = 0.0 + 0.1 * (double)z[4];      n[5] = 0.0 + 2.0 * (double)z[5];
-        n[6] = 0.0 + 1.0 * (double)z[6];      n[7] = 0.0 + 5.0 * (double)z[7];
+        n[0] = (double)(2.0f * z[0]);         n[1] = (double)(10000.0f * z[1]);
+        n[2] = (double)(5.0f * z[2]);         n[3] = (double)(3.0f * z[3]);
+        n[4] = (double)(0.1f * z[4]);         n[5] = (double)(2.0f * z[5]);
+        n[6] = (double)(1.0f * z[6]);         n[7] = (double)(5.0f * z[7]);
     }
     // One work item of a cooperative reset: generator block `blk` (0 or 1) of the lane with key `k` -> image rows
     // 4 blk .. 4 blk + 3 = initial values of state rows {0,1,2,3} / {4,5,6,10}; same values, operation by operation,
@@ -83,13 +85,11 @@ struct ChemicalReactor {
         const u32x4 x = k.block(STREAM_RESET + blk);
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
         const bool hi = blk != 0u;
-        const double sd[4] = {hi ? 0.1 : 2.0, hi ? 2.0 : 10000.0, hi ? 1.0 : 5.0, hi ? 5.0 : 3.0};            // :93-103
-        const double mean[4] = {hi ? 0.5 : 320.0, hi ? 95.0 : 253312.5, hi ? 295.0 : 50.0, hi ? 60.0 : 30.0};
+        const float sd[4] = {hi ? 0.1f : 2.0f, hi ? 2.0f : 10000.0f, hi ? 1.0f : 5.0f, hi ? 5.0f : 3.0f};          // :93-103
+        const float mean[4] = {hi ? 0.5f : 320.0f, hi ? 95.0f : 253312.5f, hi ? 295.0f : 50.0f, hi ? 60.0f : 30.0f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double n = 0.0 + sd[q] * (double)probit_normal(w[q], k.tab);
-            img[(4u * blk + (uint32_t)q) * 64u + owner] = (float)(mean[q] + n);
-        }
+        for (int q = 0; q < 4; ++q)     // == (float)((double)mean + (double)(sd * z)): exact in double, rounded once
+            img[(4u * blk + (uint32_t)q) * 64u + owner] = mean[q] + sd[q] * probit_normal(w[q], k.tab);
     }
     __device__ static void reset_readback(const float *img, unsigned lane, float (&s)[S])
     {
@@ -305,18 +305,20 @@ struct PowerGrid {
     }
     __device__ static void draw_init(const RngKey &k, double (&n)[KR])
     {
+        // "nig-philox-v2": float32 draws (normals sd * z; the load factor fma(0.4, u, -0.2) with u the 24-bit uniform,
+        // exact in float32), widened to the doubles init() takes -- see reset_item_to for what that buys
         float z[23];
         double u[8];
         gen_normals<23>(k, STREAM_RESET, z);
         gen_uniforms<8>(k, STREAM_RESET + 16u, u);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            n[i] = 0.0 + 0.01 * (double)z[i];
-            n[8 + i] = 0.0 + 2.0 * (double)z[8 + i];
-            n[16 + i] = -0.2 + (0.2 - -0.2) * u[i];                      // uniform: low + (high-low)*u
+            n[i] = (double)(0.01f * z[i]);
+            n[8 + i] = (double)(2.0f * z[8 + i]);
+            n[16 + i] = (double)__builtin_fmaf(0.4f, (float)u[i], -0.2f);      // uniform(-0.2, 0.2): low + (high - low) * u
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) n[24 + i] = 0.0 + 10.0 * (double)z[16 + i];
+        for (int i = 0; i < 7; ++i) n[24 + i] = (double)(10.0f * z[16 + i]);
     }
     __device__ static void draw_step(const RngKey &k, float (&n)[KS])
     {
@@ -352,24 +354,26 @@ struct PowerGrid {
         const u32x4 x = k.block(STREAM_RESET + (uni ? 10u + blk : blk));     // uniforms: STREAM_RESET + 16 + (blk - 6)
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
         const bool hi = (blk & 1u) != 0;                                     // second half of an 8-vector
+        // init() of draw_init()'s values without a float64 instruction: with a float32 draw d and a float32-representable
+        // offset, (float)(off + (double)d) is the exactly computed sum rounded once = off + d in float32, and
+        // (float)(b * (1.0 + (double)d)) = the exactly computed b + b d rounded once = fma(b, d, b).
         if (!uni) {
-            // value = (float)(off + (0.0 + sd * z)): V 1.0 / 0.01 (:98), gen base_load / 2.0 (:101), flows (none) / 10.0 (:108)
-            const double sd = blk < 2u ? 0.01 : (blk < 4u ? 2.0 : 10.0);
+            // V 1.0 + 0.01 z (:98), gen base_load + 2.0 z (:101), flows 10.0 z (:108)
+            const float sd = blk < 2u ? 0.01f : (blk < 4u ? 2.0f : 10.0f);
             const uint32_t row0 = (blk < 4u ? 1u : 9u) + 4u * blk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double off = blk < 2u ? 1.0 : (blk < 4u ? (hi ? base_load(4 + q) : base_load(q)) : 0.0);
-                const double d = 0.0 + sd * (double)probit_normal(w[q], k.tab);
-                const float v = (float)(off + d);      // flows: 0.0 + d == d (d is never -0.0)
+                const float off = blk < 2u ? 1.0f : (blk < 4u ? (float)(hi ? base_load(4 + q) : base_load(q)) : 0.0f);
+                const float v = off + sd * probit_normal(w[q], k.tab);      // flows: 0.0 + d == d (d is never -0.0)
                 if (q < 3 || blk != 5u) put(row0 + (uint32_t)q, v);   // z[23] does not exist
             }
             if (blk == 0u) put(0u, 0.0f);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double nn = -0.2 + (0.2 - -0.2) * u01(w[q]);           // :104 uniform: low + (high-low)*u
-                const double b = hi ? base_load(4 + q) : base_load(q);
-                put(17u + 4u * (blk - 6u) + (uint32_t)q, (float)(b * (1.0 + nn)));   // :105
+                const float nn = __builtin_fmaf(0.4f, u01f(w[q]), -0.2f);    // :104 uniform(-0.2, 0.2)
+                const float b = (float)(hi ? base_load(4 + q) : base_load(q));
+                put(17u + 4u * (blk - 6u) + (uint32_t)q, __builtin_fmaf(b, nn, b));   // :105 base * (1 + factor)
             }
         }
     }
@@ -386,9 +390,9 @@ struct PowerGrid {
         bool v_ok = true, g_ok = true;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v_ok = v_ok && (s[1 + i] >= 0.95f) && (s[1 + i] <= 1.05f);   // weak Python floats -> float32
+            v_ok = v_ok & (s[1 + i] >= 0.95f) & (s[1 + i] <= 1.05f);     // weak Python floats -> float32.  (& not &&: hipcc turns a long short-circuit chain into a cascade of exec-mask branches)
             const float ng = s[9 + i] + a[i];                            // float32 add, :29
-            g_ok = g_ok && (ng >= 0.0f) && ((double)ng <= 100.0);        // vs fp64 array np.ones(8)*100
+            g_ok = g_ok & (ng >= 0.0f) & ((double)ng <= 100.0);          // vs fp64 array np.ones(8)*100
         }
         uint32_t v = (fabsf(s[0]) < 0.5f) ? 0u : 1u;                     // :14
         v |= v_ok ? 0u : 2u;
@@ -447,7 +451,7 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const double ng = (double)s[9 + i] + a[i];                   // float64 add, :29
-            g_ok = g_ok && (ng >= 0.0) && (ng <= 100.0);
+            g_ok = g_ok & (ng >= 0.0) & (ng <= 100.0);
         }
         return v | (g_ok ? 0u : 4u);
     }
@@ -526,7 +530,7 @@ struct PowerGrid {
     {
         bool bad = fabsf(f) > 1.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bad = bad || (v[i] < 0.9f) || (v[i] > 1.1f);
+        for (int i = 0; i < 8; ++i) bad = bad | (v[i] < 0.9f) | (v[i] > 1.1f);
         return bad;
     }
     __device__ static bool done(const float (&n)[S])
@@ -651,11 +655,11 @@ struct RobotAssembly {
     {
         bool f_ok = true, c_ok = true, v_ok = true;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) f_ok = f_ok && (fabsf(s[18 + i]) < 50.0f);          // :15-16
-        c_ok = ((double)s[0] >= -0.5) && ((double)s[0] <= 0.5) && ((double)s[1] >= -0.5) &&
-               ((double)s[1] <= 0.5) && ((double)s[2] >= 0.0) && ((double)s[2] <= 0.8);   // :24-26 fp64 bounds
+        for (int i = 0; i < 3; ++i) f_ok = f_ok & (fabsf(s[18 + i]) < 50.0f);           // :15-16
+        c_ok = ((double)s[0] >= -0.5) & ((double)s[0] <= 0.5) & ((double)s[1] >= -0.5) &
+               ((double)s[1] <= 0.5) & ((double)s[2] >= 0.0) & ((double)s[2] <= 0.8);     // :24-26 fp64 bounds
 #pragma unroll
-        for (int i = 0; i < 7; ++i) v_ok = v_ok && (fabsf(s[7 + i]) < 2.0f);            // :30-32
+        for (int i = 0; i < 7; ++i) v_ok = v_ok & (fabsf(s[7 + i]) < 2.0f);             // :30-32
         return (f_ok ? 0u : 1u) | (c_ok ? 0u : 2u) | (v_ok ? 0u : 4u);
     }
 
@@ -751,9 +755,9 @@ struct RobotAssembly {
     {
         bool d = n[23] > 0.95f;                                          // :231
 #pragma unroll
-        for (int i = 0; i < 3; ++i) d = d || (fabsf(n[18 + i]) > 80.0f); // :235
-        const bool inside = ((double)n[0] >= -0.6) && ((double)n[0] <= 0.6) && ((double)n[1] >= -0.6) &&
-                            ((double)n[1] <= 0.6) && ((double)n[2] >= -0.1) && ((double)n[2] <= 0.9);   // :239-242
+        for (int i = 0; i < 3; ++i) d = d | (fabsf(n[18 + i]) > 80.0f);  // :235
+        const bool inside = ((double)n[0] >= -0.6) & ((double)n[0] <= 0.6) & ((double)n[1] >= -0.6) &
+                            ((double)n[1] <= 0.6) & ((double)n[2] >= -0.1) & ((double)n[2] <= 0.9);     // :239-242
         return d || !inside;
     }
 };

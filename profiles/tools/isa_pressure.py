@@ -49,11 +49,12 @@ for no, l in enumerate(lines):
     ins.append((a + no, op, d, u))
 
 live = set()
-prof = []
-for (no, op, d, u) in reversed(ins):
-    live -= set(d)
-    live |= set(u)
-    prof.append((no, op, len(live)))
+for _pass in range(3):                 # a loop body: live-out at the bottom = live-in at the top (fixpoint)
+    prof = []
+    for (no, op, d, u) in reversed(ins):
+        live -= set(d)
+        live |= set(u)
+        prof.append((no, op, len(live)))
 prof.reverse()
 carried = sorted(live)
 print(f"{len(ins)} instructions; live-in at the top: {len(carried)} registers")
@@ -62,3 +63,26 @@ print("peak", peak)
 for i in range(0, len(prof), every):
     no, op, n = prof[i]
     print(f"  line {no:6d} {op:28s} live {n}")
+
+# registers live at the peak, with the line and opcode of their latest definition above it (or "carried")
+pk = peak[0]
+live2 = set(carried)
+lastdef = {}
+for (no, op, d, u) in ins:
+    if no > pk:
+        break
+    for r in d:
+        lastdef[r] = (no, op)
+live_at = set()
+l = set(carried)
+for _p in range(2):
+    for (no, op, d, u) in reversed(ins):
+        l -= set(d)
+        l |= set(u)
+        if no == pk:
+            live_at = set(l)
+by = {}
+for r in sorted(live_at):
+    by.setdefault(lastdef.get(r, (0, "carried")), []).append(r)
+for k in sorted(by):
+    print(f"   def line {k[0]:6d} {k[1]:24s} -> v{by[k]}")

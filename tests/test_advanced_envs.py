@@ -149,7 +149,9 @@ def test_oracle_matches_independent_numpy_restatement(oracle, key, flavor):
     ok = np.isfinite(nxt).all(1) & np.isfinite(o["state_next"]).all(1)
     assert ok.mean() > 0.95
     assert rel_err(o["state_next"][ok], nxt[ok], floor=1e-4).max() <= 2e-5
-    assert rel_err(o["reward"][ok], rew[ok], floor=1.0).max() <= 2e-5
+    # the reward is a sum of exponentials as steep as exp(-|f - 50| / 0.1) (advanced_power_grid.py:436-482): one float32
+    # ulp in the exponent's argument is up to ~1e-5 relative in that term, on top of the different exp implementations
+    assert rel_err(o["reward"][ok], rew[ok], floor=1.0).max() <= 5e-5
     # discrete outputs agree except where a threshold sits inside that rounding band
     for name, got, want in (("terminated", o["terminated"], term), ("truncated", o["truncated"], trunc),
                             ("mask", o["viol_mask"], mask), ("shutdown", o["shutdown"], shut)):

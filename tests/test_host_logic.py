@@ -210,6 +210,18 @@ def test_constant_division_is_correctly_rounded(tmp_path):
     assert out.stdout.count("mismatches=0") == len(consts), out.stdout
 
 
+def test_probit_table_with_folded_scale_is_bit_identical(tmp_path):
+    """The normal transform's table stores {c0, c1 2^-18, c2 2^-36, c3 2^-54} and the position in a piece is taken as
+    an integer (one multiply less per normal): over all 768 x 2^18 inputs the result has the same bits as the unscaled
+    evaluation (tests/probit_scale_check.c)."""
+    import subprocess
+    exe = tmp_path / "probit_scale_check"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "probit_scale_check.c"), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches=0" in out.stdout, out.stdout
+
+
 def test_stale_library_is_never_rebuilt_under_a_profiler(monkeypatch):
     """ADVICE (round 1): importing the package inside a rocprofv3-preloaded process rebuilt a stale libnig.so
     there (hipcc -> sh -c -> clang++ from a GPU-initialised process).  _build.ensure() must refuse instead."""
