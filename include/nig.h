@@ -427,6 +427,18 @@ int nig_mixed_rollout(nig_mixed *m, int32_t n_steps, const float *action_ring, i
 int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, int32_t n_handles, int32_t n_steps,
                       const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
                       float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream);
+/* The same launch also returning the observation of every env.step (the obs of base.py:157-213's return tuple; what
+ * get_dataset stores per transition, chemical_reactor.py:395-412, power_grid.py:234-249): obs_out float
+ * [n_steps][S_max][ld_obs], the padded SoA layout of the state matrix per step -- handle k writes rows < S_k of its
+ * columns [lane_offsets[k], +batch_k) of step s at obs_out + s*obs_step_stride (>= S_max*ld_obs, or 0 = overwrite),
+ * rows >= S_k are not touched.  Needs reward_out and flags_out.  nig_mixed_rollout_obs: ld_obs = the batch's ld. */
+int nig_rollout_mixed_obs(nig_handle *const *handles, const int64_t *lane_offsets, int32_t n_handles, int32_t n_steps,
+                          const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
+                          float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                          float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream);
+int nig_mixed_rollout_obs(nig_mixed *m, int32_t n_steps, const float *action_ring, int64_t slot_stride, int32_t ring_len,
+                          float *reward_out, uint32_t *flags_out, int64_t out_stride, float *obs_out, int64_t obs_step_stride,
+                          void *stream);
 
 /* Fill float [A][ld_act] with the synthetic uniform [-1,1) actions of stream
  * "action" for launch counter `t` (bench / parity workload generator). */

@@ -35,7 +35,7 @@ SYMBOLS = [
     "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
     "nig_step64", "nig_step_host64", "nig_reduce_metrics",
     "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
-    "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step",
+    "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step", "nig_rollout_mixed_obs", "nig_mixed_rollout_obs",
     "nig_tune", "nig_tune_get",
 ]
 
@@ -89,7 +89,13 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    _build.ensure()
+    override = os.environ.get("NIG_LIB_PATH")
+    if override:
+        # an experiment's library variant (profiles/mkvariant.sh) for same-box A/B runs: loaded in place of libnig.so,
+        # which is never overwritten (an interrupted A/B script used to leave a variant behind as "current")
+        path = override
+    else:
+        _build.ensure()
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -147,6 +153,8 @@ def lib():
     L.nig_mixed_rollout.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64, vp]
     L.nig_mixed_step.argtypes = [vp, vp, vp, vp, vp]
     L.nig_rollout_mixed.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, i32, vp, i64, i64, i32, vp, vp, i64, vp]
+    L.nig_rollout_mixed_obs.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
+    L.nig_mixed_rollout_obs.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64, vp, i64, vp]
     _lib = L
     return L
 

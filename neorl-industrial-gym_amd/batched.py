@@ -591,9 +591,15 @@ class MixedBatchedEnv:
         self._fan(f)
         return self.obs, self.reward, self.flags
 
-    def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out=None, flags_out=None):
-        """action_ring: float32 [R, A_max, LD]; optional reward/flags outputs [n_steps, LD]."""
+    def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out=None, flags_out=None, obs_out=None):
+        """action_ring: float32 [R, A_max, LD]; optional reward/flags outputs [n_steps, LD]; optional obs_out float32
+        [n_steps, S_max, LD]: the observation every env.step returns, in the padded SoA layout of the state matrix
+        (rows >= S of a segment are left as they are)."""
         assert action_ring.shape[1:] == (self.A_max, self.ld)
+        if obs_out is not None:
+            assert reward_out is not None and obs_out.dtype == torch.float32 and obs_out.dim() == 3
+            assert obs_out.shape[0] >= n_steps and obs_out.shape[1] >= self.S_max and obs_out.shape[2] == self.ld
+            assert obs_out.stride(2) == 1 and obs_out.stride(1) == self.ld
         if self.fused:
             assert action_ring.dtype == torch.float32 and action_ring.stride(2) == 1 and action_ring.stride(1) == self.ld
             assert (reward_out is None) == (flags_out is None)
@@ -605,16 +611,18 @@ class MixedBatchedEnv:
                 assert (flags_out.stride(0) if flags_out.dim() == 2 else 0) == os_
             L = self.envs[0]._L
             with torch.cuda.device(self.envs[0]._dev_index):
-                _lib.check(L.nig_rollout_mixed(self._hs, self._offs, len(self.envs), int(n_steps),
-                                               C.c_void_p(action_ring.data_ptr()), self.ld, action_ring.stride(0),
-                                               action_ring.shape[0], _ptr(reward_out), _ptr(flags_out), os_,
-                                               self.envs[0]._stream()))
+                _lib.check(L.nig_rollout_mixed_obs(self._hs, self._offs, len(self.envs), int(n_steps),
+                                                   C.c_void_p(action_ring.data_ptr()), self.ld, action_ring.stride(0),
+                                                   action_ring.shape[0], _ptr(reward_out), _ptr(flags_out), os_,
+                                                   _ptr(obs_out), self.ld, 0 if obs_out is None else obs_out.stride(0),
+                                                   self.envs[0]._stream()))
             return
 
         def f(env, o):
             env.rollout(n_steps, action_ring[:, :env.action_dim, o:o + env.batch],
                         None if reward_out is None else reward_out[:, o:o + env.batch],
-                        None if flags_out is None else flags_out[:, o:o + env.batch])
+                        None if flags_out is None else flags_out[:, o:o + env.batch],
+                        None if obs_out is None else obs_out[:, :env.state_dim, o:o + env.batch])
         self._fan(f)
 
     def fill_actions(self, t: int, out: torch.Tensor):

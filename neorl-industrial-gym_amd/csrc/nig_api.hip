@@ -888,6 +888,15 @@ int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, i
                       const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
                       float *reward_out, uint32_t *flags_out, int64_t out_stride, void *stream)
 {
+    return nig_rollout_mixed_obs(handles, lane_offsets, n_handles, n_steps, action_ring, ld_act, slot_stride, ring_len, reward_out,
+                                 flags_out, out_stride, nullptr, 0, 0, stream);
+}
+
+int nig_rollout_mixed_obs(nig_handle *const *handles, const int64_t *lane_offsets, int32_t n_handles, int32_t n_steps,
+                          const float *action_ring, int64_t ld_act, int64_t slot_stride, int32_t ring_len,
+                          float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                          float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
+{
     if (!handles || !lane_offsets || n_handles <= 0 || n_handles > NIG_MIXED_MAX_SEGMENTS)
         return fail(NIG_ERR_INVALID, "nig_rollout_mixed: 1..12 handles%s");
     if (!action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: bad argument%s");
@@ -897,8 +906,10 @@ int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, i
         return fail(NIG_ERR_INVALID, "nig_rollout_mixed: ld_act outside [1, 2^26] or slot_stride >= 2^32%s");
     if (out_stride != 0 && out_stride > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: out_stride > 2^26%s");
     if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: n_steps*out_stride >= 2^32%s");
+    if (obs_out && !reward_out) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: an observation trajectory needs reward_out and flags_out too%s");
+    if (obs_out && (ld_obs <= 0 || ld_obs > NIG_MAX_PITCH)) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: ld_obs outside [1, 2^26]%s");
     int order[NIG_MIXED_MAX_SEGMENTS];
-    int a_max = 0;
+    int a_max = 0, s_max = 0;
     for (int k = 0; k < n_handles; ++k) {
         const nig_handle *h = handles[k];
         if (!h) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: NULL handle%s");
@@ -907,8 +918,12 @@ int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, i
             return fail(NIG_ERR_INVALID, "nig_rollout_mixed: a segment does not fit the row pitch%s");
         if ((int64_t)h->t + n_steps > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: launch counter would wrap%s");
         if (SPECS[h->env].action_dim > a_max) a_max = SPECS[h->env].action_dim;
+        if (SPECS[h->env].state_dim > s_max) s_max = SPECS[h->env].state_dim;
+        if (obs_out && lane_offsets[k] + h->B > ld_obs) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: a segment does not fit ld_obs%s");
         order[k] = k;
     }
+    if (obs_out && obs_step_stride != 0 && obs_step_stride < (int64_t)s_max * ld_obs)
+        return fail(NIG_ERR_INVALID, "nig_rollout_mixed: obs_step_stride smaller than one [S_max][ld_obs] step%s");
     if (slot_stride < (int64_t)a_max * ld_act) return fail(NIG_ERR_INVALID, "nig_rollout_mixed: slot_stride smaller than one [A_max][ld_act] slot%s");
     for (int i = 1; i < n_handles; ++i)           // insertion sort: most expensive env first, ties in segment order
         for (int j = i; j > 0 && env_cost(handles[order[j]]->env) > env_cost(handles[order[j - 1]]->env); --j) {
@@ -929,12 +944,13 @@ int nig_rollout_mixed(nig_handle *const *handles, const int64_t *lane_offsets, i
         q.s.t_ptr = nullptr; q.s.t_off = h->t;
         q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride;
         q.out_stride = (uint32_t)out_stride; q.block0 = 0;
+        if (obs_out) { q.obs_out = obs_out + o; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = 0; }
         blocks += grid_for(h->B);
         m.blk_end[i] = blocks;
         m.env[i] = h->env;
     }
     HIP_TRY(hipSetDevice(handles[0]->device));
-    nig_launch_mixed_rollout(reward_out ? 1 : 0, m, blocks, (hipStream_t)stream);
+    nig_launch_mixed_rollout(!reward_out ? 0 : (obs_out ? 2 : 1), m, blocks, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < n_handles; ++k) handles[k]->t += (uint32_t)n_steps;
     return NIG_OK;
@@ -1041,6 +1057,15 @@ int nig_mixed_rollout(nig_mixed *m, int32_t n_steps, const float *action_ring, i
     if (!m) return fail(NIG_ERR_INVALID, "nig_mixed_rollout: NULL handle%s");
     return nig_rollout_mixed(m->seg, m->off, m->n, n_steps, action_ring, m->ld, slot_stride, ring_len, reward_out, flags_out,
                              out_stride, stream);
+}
+
+int nig_mixed_rollout_obs(nig_mixed *m, int32_t n_steps, const float *action_ring, int64_t slot_stride, int32_t ring_len,
+                          float *reward_out, uint32_t *flags_out, int64_t out_stride, float *obs_out, int64_t obs_step_stride,
+                          void *stream)
+{
+    if (!m) return fail(NIG_ERR_INVALID, "nig_mixed_rollout_obs: NULL handle%s");
+    return nig_rollout_mixed_obs(m->seg, m->off, m->n, n_steps, action_ring, m->ld, slot_stride, ring_len, reward_out, flags_out,
+                                 out_stride, obs_out, m->ld, obs_step_stride, stream);
 }
 
 // ---- the path's one collective: all-gather of the partial tallies over RCCL ----------------------

@@ -7,9 +7,8 @@
 // same results bit for bit.  One launch instead of one per segment: no per-kernel tails (a 150 k-lane PowerGrid
 // segment alone fills the chip 1.14 times: its second round ran at 14 % occupancy), no launch fan-out.
 // The price of one kernel for all envs: every block runs under ONE register allocation.  It is set for three waves
-// per SIMD (168 registers): PowerGrid's body, which wants ~185 and runs at two waves per SIMD as a kernel of its
-// own, spills ~70 dwords here, but the other six bodies and the chip as a whole gain more from the third wave than
-// PowerGrid loses (1 048 576 lanes, README set: 4.31 -> 3.75 ms per 250 steps; LDS, 45 KB per block, allows three).
+// per SIMD (168 registers; LDS, 45 KB per block, allows three).  PowerGrid's register-resident body wants ~185 and
+// spilled ~70 dwords here (round 2); since round 3 its whole blocks run the LDS-resident body (nig_pg_lds.hpp, ~110).
 #include "nig_kernels.hpp"
 
 namespace nig {
@@ -18,14 +17,16 @@ template <int OUT>
 struct MixedLds {
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int BYTES =
-        cmax(cmax(cmax(RolloutLds<ChemicalReactor, OUT>::BYTES, RolloutLds<PowerGrid, OUT>::BYTES),
+        cmax(cmax(cmax(RolloutLds<ChemicalReactor, OUT>::BYTES, cmax(RolloutLds<PowerGrid, OUT>::BYTES, PgLds<BLOCK>::BYTES)),
                   cmax(RolloutLds<RobotAssembly, OUT>::BYTES, RolloutLds<AdvancedChemicalReactor, OUT>::BYTES)),
              cmax(cmax(RolloutLds<AdvancedPowerGrid, OUT>::BYTES, RolloutLds<HVACControl, OUT>::BYTES),
                   cmax(cmax(RolloutLds<WaterTreatment, OUT>::BYTES, RolloutLds<SteelAnnealing, OUT>::BYTES),
                        RolloutLds<SupplyChain, OUT>::BYTES)));
 };
 
-// OUT: 0 = no per-step outputs, 1 = reward + flag word rows (the padded [n_steps][ld] matrices).
+// OUT: 0 = no per-step outputs, 1 = reward + flag word rows (the padded [n_steps][ld] matrices), 2 = + the observation
+// every env.step returns, as rows of a padded [n_steps][S_max][ld] trajectory (segment k fills rows < S_k of its own
+// columns; rows >= S_k are never touched) -- what get_dataset stores per step (chemical_reactor.py:395-412).
 template <int OUT>
 __global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs m)
 {
@@ -45,7 +46,14 @@ __global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs
     // unpaired form for ChemicalReactor (its launch-counter parity is per handle), predicated lanes (ragged segments)
     switch (env) {
     case NIG_ENV_CHEMICAL_REACTOR: rollout_body<ChemicalReactor, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_POWER_GRID: rollout_body<PowerGrid, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_POWER_GRID:
+        // whole blocks of a handle on which no lane can be frozen: the LDS-resident body (nig_pg_lds.hpp; ~110 registers,
+        // where the register-resident one spilled ~70 dwords under this kernel's 168) -- bit-identical, tests/test_gpu_mixed.py
+        if (base + BLOCK <= q.s.B && (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0)
+            pg_lds_rollout_body<OUT, BLOCK>(q, base, smem);
+        else
+            rollout_body<PowerGrid, OUT, false, false>(q, base, smem);
+        break;
     case NIG_ENV_ROBOT_ASSEMBLY: rollout_body<RobotAssembly, OUT, false, false>(q, base, smem); break;
     case NIG_ENV_ADV_CHEMICAL_REACTOR: rollout_body<AdvancedChemicalReactor, OUT, false, false>(q, base, smem); break;
     case NIG_ENV_ADV_POWER_GRID: rollout_body<AdvancedPowerGrid, OUT, false, false>(q, base, smem); break;
@@ -62,5 +70,6 @@ void nig_launch_mixed_rollout(int out_mode, const nig::MixedArgs &m, unsigned gr
 {
     using namespace nig;
     if (out_mode == 0) hipLaunchKernelGGL((mixed_rollout_kernel<0>), dim3(grid), dim3(BLOCK), 0, st, m);
-    else hipLaunchKernelGGL((mixed_rollout_kernel<1>), dim3(grid), dim3(BLOCK), 0, st, m);
+    else if (out_mode == 1) hipLaunchKernelGGL((mixed_rollout_kernel<1>), dim3(grid), dim3(BLOCK), 0, st, m);
+    else hipLaunchKernelGGL((mixed_rollout_kernel<2>), dim3(grid), dim3(BLOCK), 0, st, m);
 }

@@ -245,10 +245,20 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                 // the image now holds the wave's 64 post-step rows: row-major float4 64 j + lane sits at 64 j + rd
                 v4f *oo = reinterpret_cast<v4f *>(obs_row);
                 v4f v[8];
+#ifdef NIG_DIAG_PG_NOLDSREAD           // (diagnostic builds only, profiles/r03/pg_store_probe2.sh: what do the transposed reads cost?)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v4f w = {ngen7, l7, (float)j, ngen7}; v[j] = w; }
+#else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = img[64 * j + rd];
+#endif
+#ifdef NIG_DIAG_PG_NOSTORE             // (diagnostic: the reads without the stores)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(v[j]));
+#else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, v[j]);
+#endif
             }
             if constexpr (OUT >= 2) obs_row += q.obs_step_stride;
             // ---- IndustrialEnv.reset for the lanes that finished (base.py:133-155), wave-cooperative: work item =
@@ -281,6 +291,12 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
     }
     act_next = ring + (size_t)slot * q.slot_stride;
     __builtin_amdgcn_s_waitcnt(0x0F70);            // prologue loads drained here, not in the loop header (rollout_body)
+#ifdef NIG_DIAG_PG_STAGGER             // (diagnostic builds only: start the four waves of a SIMD a quarter step apart)
+    {
+        const unsigned ph = ((wave >> 2) + 2u * (blockIdx.x & 1u)) & 3u;
+        for (unsigned k = 0; k < ph * NIG_DIAG_PG_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     int it = q.it0;
     for (; it < q.n_steps; ++it) one_step(buf[0], it);
 #pragma unroll

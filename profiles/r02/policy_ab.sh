@@ -2,6 +2,7 @@
 export NIG_NO_AUTOBUILD=1
 mkdir -p gpurun_out
 cp neorl-industrial-gym_amd/libnig.so /tmp/libnig_orig.so
+trap 'cp /tmp/libnig_orig.so neorl-industrial-gym_amd/libnig.so' EXIT   # (round-2 script, kept as the record of that A/B: it swaps libnig.so in place; new A/Bs load variants through NIG_LIB_PATH, profiles/ab.sh)
 last=$(echo $1 | awk '{print $NF}')
 cp neorl-industrial-gym_amd/libnig_$last.so neorl-industrial-gym_amd/libnig.so
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_abi_round2.py tests/test_spec_envs.py -m gpu -x -q -k "policy or pid or dataset or evaluate or agents" > gpurun_out/policy_tests.txt 2>&1 || { tail -30 gpurun_out/policy_tests.txt; cp /tmp/libnig_orig.so neorl-industrial-gym_amd/libnig.so; exit 1; }

@@ -64,7 +64,12 @@ class CMixed:
     def reset(self):
         self.ni._lib.check(self.L.nig_mixed_reset(self.h, _stream()))
 
-    def rollout(self, T, ring, rew=None, fl=None):
+    def rollout(self, T, ring, rew=None, fl=None, obs=None):
+        if obs is not None:                    # + the observation rows of every step, padded [T][S_max][ld]
+            self.ni._lib.check(self.L.nig_mixed_rollout_obs(
+                self.h, T, C.c_void_p(ring.data_ptr()), ring.stride(0), ring.shape[0], C.c_void_p(rew.data_ptr()),
+                C.c_void_p(fl.data_ptr()), rew.stride(0), C.c_void_p(obs.data_ptr()), obs.stride(0), _stream()))
+            return
         self.ni._lib.check(self.L.nig_mixed_rollout(
             self.h, T, C.c_void_p(ring.data_ptr()), ring.stride(0), ring.shape[0],
             None if rew is None else C.c_void_p(rew.data_ptr()), None if fl is None else C.c_void_p(fl.data_ptr()),
@@ -87,7 +92,8 @@ def _segments(total, n=7):
 
 @pytest.mark.parametrize("names", [SEVEN, SURVEY7], ids=["readme7", "survey7"])
 def test_mixed_one_launch_at_full_size(ni, oracle, names):
-    """1 048 576 lanes, seven segments, 60 fused steps in ONE launch."""
+    """1 048 576 lanes, seven segments, 60 fused steps in ONE launch, every step's observation rows written to the
+    padded [T][S_max][ld] trajectory (mixed_rollout_kernel<2>)."""
     total, T, R = 1048576, 60, 8
     counts = _segments(total)
     mix = CMixed(ni, names, counts)
@@ -96,8 +102,9 @@ def test_mixed_one_launch_at_full_size(ni, oracle, names):
     ring = mix.ring(R)
     rew = torch.full((T, mix.ld), float("nan"), dtype=torch.float32, device="cuda:0")
     fl = torch.zeros(T, mix.ld, dtype=torch.int32, device="cuda:0")
+    obs = torch.full((T, mix.S, mix.ld), float("nan"), dtype=torch.float32, device="cuda:0")
     mix.reset()
-    mix.rollout(T, ring, rew, fl)
+    mix.rollout(T, ring, rew, fl, obs)
     torch.cuda.synchronize()
     st = mix.state()
     Lb = ni._lib
@@ -126,11 +133,18 @@ def test_mixed_one_launch_at_full_size(ni, oracle, names):
         A = solo.action_dim
         srew = torch.zeros(T, n, dtype=torch.float32, device="cuda:0")
         sfl = torch.zeros(T, n, dtype=torch.int32, device="cuda:0")
+        sobs = torch.zeros(T, solo.state_dim, solo.ld, dtype=torch.float32, device="cuda:0")
         solo.reset()
-        solo.rollout(T, ring[:, :A, o:o + n], srew, sfl)
+        solo.rollout(T, ring[:, :A, o:o + n], srew, sfl, sobs)
         torch.cuda.synchronize()
         assert torch.equal(solo.state_soa.view(torch.int32), st[:solo.state_dim, o:o + n].view(torch.int32)), name
         assert torch.equal(srew, rew[:, o:o + n]) and torch.equal(sfl, fl[:, o:o + n]), name
+        # the observation rows of every step == the stand-alone kernel's trajectory; rows >= S of the segment untouched
+        assert torch.equal(sobs[:, :, :n].view(torch.int32), obs[:, :solo.state_dim, o:o + n].view(torch.int32)), name
+        assert bool(torch.isnan(obs[:, solo.state_dim:, o:o + n]).all()), name
+        keep = (sfl[T - 1] & Lb.FLAG_DID_RESET) == 0          # lanes that did not reset in the last step: its row is the final state
+        assert torch.equal(obs[T - 1, :solo.state_dim, o:o + n][:, keep].view(torch.int32), st[:solo.state_dim, o:o + n][:, keep].view(torch.int32)), name
+        del sobs
         # ... and the stand-alone kernel's first / last wave == the CPU oracle with the SAME actions
         for lo in (0, n - 64):
             acts = ring[:, :A, o + lo:o + lo + 64].permute(0, 2, 1).contiguous().cpu().numpy()      # [R, 64, A]
