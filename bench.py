@@ -152,12 +152,16 @@ def settle(torch, wl, seconds):
     The metric is sustained throughput, so the ramp is kept out of the timed region.  Returns the launches run."""
     n = 0
     if seconds > 0:
+        # at most ~2 000 kernel dispatches between two synchronisations: a hipGraph replay is 251 of them, and 32 replays
+        # in flight (8 032 dispatches) is what the one hung `rocprofv3 --pmc` pass of round 2 had queued behind the
+        # profiler's per-dispatch counter packets (profiles/README.md); 10 replays (2 510) had always completed
+        per = max(1, min(32, 2000 // max(1, wl.kernels_per_launch() + 1)))
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
-            for _ in range(32):
+            for _ in range(per):
                 wl.launch()
             torch.cuda.synchronize()
-            n += 32
+            n += per
     return n
 
 
@@ -400,6 +404,9 @@ class RehearsalWorkload:
 
     def launch(self):
         pass
+
+    def kernels_per_launch(self):
+        return 1
 
     def reduce_tally(self):
         L = self.ni._lib
@@ -667,6 +674,9 @@ def measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, B, K, W,
     class _W:
         def launch(self):
             mix.rollout(P, ring, rew, fl, obs)
+
+        def kernels_per_launch(self):
+            return 1 if fused else len(mix.envs)
     wall, dev_ms = timed(torch, dist, world, comm_dev, _W(), K, W, settle_s)
     # per-env rate measured separately on its own segment size (same per-env kernels, stand-alone launch)
     per_env = {}

@@ -15,6 +15,10 @@ import sys
 from collections import defaultdict
 
 
+ROLLOUT_RX = r"rollout_kernel|rollout_wide_kernel|split_rollout_kernel"     # the fused-rollout kernel forms
+ROUND = os.environ.get("NIG_PROFILE_ROUND", "r03")                           # directory under profiles/ the record is kept in
+
+
 def load(path):
     per = defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -38,7 +42,7 @@ def main():
         cal = sorted(cal)[len(cal) // 2] if cal else None
         scale = (known / cal) if cal else None    # bytes per counter unit for dword-per-lane rows
         for k, vs in per.items():
-            if re.search(r"rollout_kernel|step_kernel", k):
+            if re.search(ROLLOUT_RX + r"|step_kernel", k):
                 vs = sorted(vs)
                 med = vs[len(vs) // 2]
                 res.setdefault(k, {})[ctr] = {"median_counter": med, "calibrated_scale_bytes_per_unit": scale,
@@ -48,7 +52,7 @@ def main():
     for k, d in res.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d and d["FETCH_SIZE"]["bytes_per_launch"] is not None:
             per_launch = d["FETCH_SIZE"]["bytes_per_launch"] + d["WRITE_SIZE"]["bytes_per_launch"]
-            env_steps = B * (P if "rollout_kernel" in k else 1)          # env-steps one kernel launch processes
+            env_steps = B * (P if re.search(ROLLOUT_RX, k) else 1)          # env-steps one kernel launch processes
             summary[k] = {"hbm_bytes_per_env_step": per_launch / env_steps, "plan_steps": P, "mode": mode,
                           "env_steps_per_launch": env_steps, "hbm_bytes_per_launch": per_launch,
                           "fetch_bytes": d["FETCH_SIZE"]["bytes_per_launch"], "write_bytes": d["WRITE_SIZE"]["bytes_per_launch"],
@@ -58,16 +62,16 @@ def main():
     print(json.dumps(summary, indent=1))
     # merge into profiles/traffic.json under the key bench.py looks up: <env>_<B>_<mode>_<outputs|step>
     outputs = args[args.index("--outputs") + 1] if "--outputs" in args else "full"
-    want = "rollout_kernel" if mode == "rollout" else "step_kernel"
+    want = ROLLOUT_RX if mode == "rollout" else "step_kernel"
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     try:
         allt = json.load(open(tpath))
     except Exception:
         allt = {}
     for k, v in summary.items():
-        if want in k:
+        if re.search(want, k):
             rec = {kk: vv for kk, vv in v.items() if kk != "detail"}
-            rec["source"] = f"profiles/r02/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on copy_rows_kernel)"
+            rec["source"] = f"profiles/{ROUND}/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on copy_rows_kernel)"
             allt[f"{env}_{B}_{mode}_{outputs if mode == 'rollout' else 'step'}"] = rec
     json.dump(allt, open(tpath, "w"), indent=1)
 

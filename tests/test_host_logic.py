@@ -328,3 +328,22 @@ def test_bench_refuses_a_world_that_differs_from_gpus():
     assert p.returncode != 0 and rec is None and "torch.distributed.run" in p.stderr
     p, rec = _run_bench(["--gpus", "1"], {"NIG_BENCH_REHEARSE": "cpu", "WORLD_SIZE": "2", "RANK": "0"})
     assert p.returncode != 0 and rec is None
+
+
+def test_oracle_under_sanitizers():
+    """SURVEY section 5 / VERDICT r02: the oracle's C restatement built with -fsanitize=address,undefined and the
+    golden-vector tests (every entry point: step, step64, reset, rollouts, policies, the MLP actor, the generator) run
+    against that build; any out-of-bounds access, use of an uninitialised-size object or undefined arithmetic aborts."""
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, NIG_ORACLE_SANITIZE="1", LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_advanced_envs.py"),
+                        os.path.join(ROOT, "tests", "test_spec_envs.py")],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    assert " passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
