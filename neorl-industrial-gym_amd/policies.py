@@ -134,6 +134,11 @@ def behaviour_policy(env_id: str, quality: str) -> DevicePolicy:
             W[1, 0], b[1] = 0.3 / 50, -0.3 * 320.0 / 50      #  temp_error*0.3
             W[2, 10], b[2] = -0.2 / 50, 0.2 * 55.0 / 50      # -level_error*0.2
             return DevicePolicy(S, A, W=W, b=b, sigma=[nl * 0.1] * 3, clip=(-1.0, 1.0))
+        if nl >= 1.0:
+            # "random": np.random.random() < (1 - 1.0) never holds (:380), so every action is uniform(-1, 1, 3) (:389):
+            # no feedback term at all (found by tests/golden/behaviour_laws.npz: the reference's law with its draws
+            # patched to zero is identically 0 here)
+            return DevicePolicy(S, A, p_uniform=1.0, uniform_range=1.0, clip=(-1.0, 1.0))
         W[0, 0], b[0] = -0.2 / 50, 0.2 * 320.0 / 50
         return DevicePolicy(S, A, W=W, b=b, sigma=[nl * 0.3, nl * 0.5, nl * 0.3], p_uniform=nl, uniform_range=1.0,
                             clip=(-1.0, 1.0))

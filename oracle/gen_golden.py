@@ -15,6 +15,8 @@ Fixture families:
   <env>_g6.npz  the G1 states stepped with genuine float64 action values                  [arg: g6]
   datasets.npz  env.get_dataset(quality) under np.random.seed(123): heads + summaries      [arg: datasets]
   baseline_agents.npz  act() sequences of benchmarks/baseline_agents.py on recorded obs   [arg: agents]
+  behaviour_laws.npz   get_dataset(quality)'s action law with its own noise draws patched to zero: (obs, action)  [arg: laws]
+  cr_info.npz   ChemicalReactor's reset / step info dicts (_get_safety_info margins) along a seeded run          [arg: info]
 Reference semantics pinned: NumPy 2.2.6; float32 actions (G1-G4) and float64 actions (G5, G6, datasets).
 """
 import json
@@ -575,8 +577,8 @@ def main():
     meta = {"numpy": np.__version__, "envs": ENVS}
     KR = {"cr": 8, "pg": 31, "ra": 7}
     g2 = {"cr": g2_cr, "pg": g2_pg, "ra": g2_ra}
-    g1_target = {"cr": 4200, "pg": 2500, "ra": 2500}
-    g3_eps = {"cr": 12, "pg": 64, "ra": 64}
+    g1_target = {"cr": 4200, "pg": 4200, "ra": 4200}       # >= 4096 tuples per env
+    g3_eps = {"cr": 64, "pg": 64, "ra": 64}                 # 64 episodes per env
     for key in ENVS:
         arr, K = harvest_g1(utils, key, g1_target[key], seed=1000 + len(key) + ord(key[0]))
         np.savez_compressed(os.path.join(OUT, f"{key}_g1.npz"), **arr)
@@ -599,7 +601,7 @@ def main():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("datasets", "g5", "g6", "agents")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("datasets", "g5", "g6", "agents", "laws", "info")):
     main()
 
 
@@ -758,3 +760,115 @@ def gen_agents():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "agents":
     gen_agents()
+
+
+LAW_ROWS = 640     # (observation, action) pairs kept per (env, quality)
+
+
+def gen_laws():
+    """The action LAW of env.get_dataset(quality) (chemical_reactor.py:364-393, power_grid.py:216-233,
+    robot_assembly.py:266-290) on >= 512 observations of the reference's own data-collection run, with the law's own
+    random draws patched to zero: np.random.normal / uniform called FROM get_dataset return 0, np.random.random / rand
+    called from it return 0.0 (so the epsilon-mixtures take their feedback branch).  The env's reset and process noise
+    (drawn inside step / reset, other frames) stays random, so the observations spread.  Stored per (env, quality): the
+    float32 observations of the dataset and the actions the reference stored for them (for ChemicalReactor the clipped
+    action, for PowerGrid / RobotAssembly the action as computed -- the reference's own conventions)."""
+    utils = load_reference()
+    real = {k: getattr(np.random, k) for k in ("normal", "uniform", "random", "rand")}
+
+    def from_law():
+        return sys._getframe(2).f_code.co_name == "get_dataset"
+
+    def normal(loc=0.0, scale=1.0, size=None):
+        if from_law():
+            return 0.0 if size is None else np.zeros(size)
+        return real["normal"](loc, scale, size)
+
+    def uniform(low=0.0, high=1.0, size=None):
+        if from_law():
+            return 0.0 if size is None else np.zeros(size)
+        return real["uniform"](low, high, size)
+
+    def random(*a):
+        return 0.0 if from_law() else real["random"](*a)
+
+    def rand(*a):
+        return 0.0 if from_law() else real["rand"](*a)
+
+    out = {}
+    np.random.normal, np.random.uniform, np.random.random, np.random.rand = normal, uniform, random, rand
+    try:
+        for key, name in ENVS.items():
+            for q in ("expert", "medium", "mixed", "random"):
+                env = utils.make(name)
+                np.random.seed(777)
+                d = env.get_dataset(q)
+                n = min(LAW_ROWS, len(d["actions"]))
+                # spread over the run rather than its head (PowerGrid / RobotAssembly episodes are a few steps long)
+                idx = np.linspace(0, len(d["actions"]) - 1, n).astype(np.int64)
+                out[f"{key}_{q}_obs"] = d["observations"][idx].astype(f32)
+                out[f"{key}_{q}_act"] = d["actions"][idx].astype(f32)
+                print(key, q, n, "of", len(d["actions"]), "|a| max", float(np.abs(d["actions"]).max()))
+    finally:
+        np.random.normal, np.random.uniform, np.random.random, np.random.rand = (real[k] for k in ("normal", "uniform", "random", "rand"))
+    np.savez_compressed(os.path.join(OUT, "behaviour_laws.npz"), **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "laws":
+    gen_laws()
+
+
+def gen_info():
+    """ChemicalReactorEnv._get_safety_info (chemical_reactor.py:307-322): the reset-time info dict and the info dict of
+    every step along a run under np.random.seed(4321) with a fixed float32 action sequence: safety_metrics sub-dict at
+    reset (the five state values), constraint_values (temp_margin, pressure_margin, level_in_bounds) at reset and per
+    step, step / violations / total_violations / critical_shutdown.  Two episodes (the second exercises reset's
+    bookkeeping: violations back to 0, total_violations kept)."""
+    utils = load_reference()
+    env = utils.make("ChemicalReactor-v0")
+    rng = np.random.Generator(np.random.PCG64(99))
+    rows = {k: [] for k in ("obs", "action", "temp_margin", "pressure_margin", "level_in_bounds", "step", "violations",
+                            "total_violations", "critical_shutdown", "is_reset", "sm_reset")}
+    dtypes = {}
+    np.random.seed(4321)
+    for ep in range(2):
+        obs, info = env.reset()
+        cv, sm = info["constraint_values"], info["safety_metrics"]
+        dtypes["temp_margin"] = type(cv["temp_margin"]).__name__
+        dtypes["level_in_bounds"] = type(cv["level_in_bounds"]).__name__
+        rows["obs"].append(obs.copy()); rows["action"].append(np.zeros(3, dtype=f32)); rows["is_reset"].append(1)
+        rows["sm_reset"].append([sm["temperature"], sm["pressure"], sm["level"], sm["emergency_stop"], sm["alarm_status"]])
+        for k in ("temp_margin", "pressure_margin"):
+            rows[k].append(float(cv[k]))
+        rows["level_in_bounds"].append(int(bool(cv["level_in_bounds"])))
+        rows["step"].append(info["step"]); rows["violations"].append(info["violations"])
+        rows["total_violations"].append(info["total_violations"]); rows["critical_shutdown"].append(0)
+        for t in range(400):
+            a = np.clip(rng.normal(0.0, 0.8, 3), -1, 1).astype(f32) + (f32(0.9) if ep == 1 else f32(0))    # episode 2 is driven hot
+            obs, reward, term, trunc, info = env.step(a)
+            cv = info["constraint_values"]
+            rows["obs"].append(obs.copy()); rows["action"].append(a); rows["is_reset"].append(0)
+            rows["sm_reset"].append([0, 0, 0, 0, 0])
+            for k in ("temp_margin", "pressure_margin"):
+                rows[k].append(float(cv[k]))
+            rows["level_in_bounds"].append(int(bool(cv["level_in_bounds"])))
+            rows["step"].append(info["step"]); rows["violations"].append(info["violations"])
+            rows["total_violations"].append(info["total_violations"]); rows["critical_shutdown"].append(int(bool(info["critical_shutdown"])))
+            if term or trunc:
+                break
+    out = {"obs": np.asarray(rows["obs"], dtype=f32), "action": np.asarray(rows["action"], dtype=f32),
+           "temp_margin": np.asarray(rows["temp_margin"], dtype=np.float64),
+           "pressure_margin": np.asarray(rows["pressure_margin"], dtype=np.float64),
+           "level_in_bounds": np.asarray(rows["level_in_bounds"], dtype=np.uint8),
+           "step": np.asarray(rows["step"], dtype=np.int32), "violations": np.asarray(rows["violations"], dtype=np.int32),
+           "total_violations": np.asarray(rows["total_violations"], dtype=np.int32),
+           "critical_shutdown": np.asarray(rows["critical_shutdown"], dtype=np.uint8),
+           "is_reset": np.asarray(rows["is_reset"], dtype=np.uint8), "sm_reset": np.asarray(rows["sm_reset"], dtype=f32),
+           "margin_type": np.array(dtypes["temp_margin"]), "bounds_type": np.array(dtypes["level_in_bounds"])}
+    np.savez_compressed(os.path.join(OUT, "cr_info.npz"), **out)
+    print("cr_info rows", len(out["step"]), "resets", int(out["is_reset"].sum()), "shutdown steps", int(out["critical_shutdown"].sum()),
+          "types", dtypes, "total_violations at end", int(out["total_violations"][-1]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "info":
+    gen_info()

@@ -151,3 +151,129 @@ def test_pg_lds_rollout_bit_identical_to_oracle_at_baseline_size(ni, wide_knob, 
     last = obs[T - 1].cpu().numpy()
     assert keep.sum() > B // 2 and np.array_equal(last[keep].view(np.uint32), got[keep].view(np.uint32))
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Reference-side pins of what round 2 held only statistically or transitively
+# ---------------------------------------------------------------------------------------------------------------
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("quality", ["expert", "medium", "mixed", "random"])
+def test_device_policy_kernel_law_against_reference(ni, key, quality):
+    """The policy kernel's action (rollout_policy_kernel / split_policy_kernel, noise amplitudes set to zero) on the
+    observations of tests/golden/behaviour_laws.npz == the reference's get_dataset law with its draws patched to zero
+    (chemical_reactor.py:364-393, power_grid.py:216-233, robot_assembly.py:266-290): 1e-5 with an absolute floor at
+    float32 resolution of O(1) terms (see tests/test_oracle_golden.py law_error); and == the host predict() bit for bit."""
+    from neorl_industrial_gym_amd.policies import behaviour_policy
+    g = dict(np.load(os.path.join(GOLDEN, "behaviour_laws.npz")))
+    obs, want = g[f"{key}_{quality}_obs"], g[f"{key}_{quality}_act"]
+    n = obs.shape[0]
+    pol = behaviour_policy(ENV_NAME[key], quality)
+    pol.sigma[:] = 0
+    pol.half_range[:] = 0
+    pol.p_uniform = np.float32(0)
+    env = ni.make_batched(ENV_NAME[key], n, autoreset=False)
+    env.reset()
+    env.set_state(obs, current_step=0)
+    env.set_policy(pol)
+    act = torch.full((1, env.action_dim, env.ld), float("nan"), dtype=torch.float32, device=env.device)
+    seen = torch.zeros(1, n, env.state_dim, dtype=torch.float32, device=env.device)
+    env.rollout_policy(1, obs_out=seen, act_out=act)
+    torch.cuda.synchronize()
+    got = act[0, :, :n].t().cpu().numpy()
+    assert np.array_equal(seen[0].cpu().numpy().view(np.uint32), obs.view(np.uint32))          # the policy acted on these rows
+    host = behaviour_policy(ENV_NAME[key], quality).predict(obs)
+    assert np.array_equal(got.view(np.uint32), host.view(np.uint32))
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 0.2)
+    assert err.max() <= 1e-5, (key, quality, float(err.max()))
+    env.close()
+
+
+def test_chemical_reactor_info_dicts_against_reference(ni):
+    """ChemicalReactorEnv._get_safety_info (chemical_reactor.py:307-322): reset-time safety_metrics values, the
+    constraint_values margins and the step / violations / total_violations / critical_shutdown entries of every info
+    dict along the reference's own seeded run (tests/golden/cr_info.npz, np.random.seed(4321), two episodes)."""
+    g = dict(np.load(os.path.join(GOLDEN, "cr_info.npz")))
+    assert str(g["margin_type"]) == "float32" and str(g["bounds_type"]) == "bool"
+    env = ni.make("ChemicalReactor-v0")
+    np.random.seed(4321)
+    i, n = 0, len(g["step"])
+    while i < n:
+        assert g["is_reset"][i] == 1
+        obs, info = env.reset()
+        assert np.array_equal(obs.view(np.uint32), g["obs"][i].view(np.uint32))
+        sm, cv = info["safety_metrics"], info["constraint_values"]
+        assert [np.float32(sm[k]) for k in ("temperature", "pressure", "level", "emergency_stop", "alarm_status")] == list(g["sm_reset"][i])
+        assert isinstance(cv["temp_margin"], np.float32) and isinstance(cv["level_in_bounds"], (bool, np.bool_))
+        assert (np.float32(cv["temp_margin"]), np.float32(cv["pressure_margin"]), int(cv["level_in_bounds"])) == \
+               (np.float32(g["temp_margin"][i]), np.float32(g["pressure_margin"][i]), int(g["level_in_bounds"][i]))
+        assert (info["step"], info["violations"], info["total_violations"]) == (g["step"][i], g["violations"][i], g["total_violations"][i])
+        i += 1
+        while i < n and g["is_reset"][i] == 0:
+            obs, reward, term, trunc, info = env.step(g["action"][i])
+            cv = info["constraint_values"]
+            # states follow the reference within the parity bar (np.exp in the concentration row), margins with them
+            assert rel_err_np(obs, g["obs"][i]) <= 1e-5, i
+            assert abs(float(cv["temp_margin"]) - g["temp_margin"][i]) <= 1e-5 * max(1.0, abs(g["temp_margin"][i]))
+            assert abs(float(cv["pressure_margin"]) - g["pressure_margin"][i]) <= 1e-5 * max(1.0, abs(g["pressure_margin"][i]))
+            assert int(cv["level_in_bounds"]) == g["level_in_bounds"][i]
+            assert (info["step"], info["violations"], info["total_violations"], int(info["critical_shutdown"])) == \
+                   (g["step"][i], g["violations"][i], g["total_violations"][i], g["critical_shutdown"][i]), i
+            i += 1
+    assert i == n
+
+
+def rel_err_np(a, b, floor=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def test_three_wave_form_rows_against_oracle_trajectories(ni, oracle):
+    """The three-wave rollout (csrc/nig_split.hpp) checked DIRECTLY against the oracle, not through the one-wave form:
+    the knob is forced, the host rule is asserted to select the three-wave kernel, and every row-major trajectory row,
+    reward and termination flag of the first and last wave of the batch is compared step by step with the oracle's
+    teacher-forced step fed by the generator's own draws (terminal observations included), then the final state."""
+    import types
+    import bench
+    name, B, T, seed = "ChemicalReactor-v0", 1024, 40, 0x5EED
+    before = ni.tune()["split_blocks"]
+    ni.tune(split_blocks=256)
+    try:
+        assert bench.rollout_kernel_name(types.SimpleNamespace(key="cr", B=B, outputs="full", ni=ni)) == "split_rollout_kernel<ChemicalReactor,3,4>"
+        env = ni.make_batched(name, B, seed=seed, autoreset=True, tally=True, max_episode_steps=23)    # truncation: resets inside the window
+        ring = torch.empty(T, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
+        for s in range(T):
+            env.fill_actions(1 + s, ring[s])
+        rew = torch.zeros(T, env.ld, dtype=torch.float32, device=env.device)
+        fl = torch.zeros(T, env.ld, dtype=torch.int32, device=env.device)
+        obs = torch.zeros(T, B, env.state_dim, dtype=torch.float32, device=env.device)
+        env.reset()
+        assert env.counter % 2 == 0                    # the first step is an odd launch counter: the PAIRED (three-wave) form applies
+        env.rollout(T, ring, rew, fl, obs)
+        torch.cuda.synchronize()
+        final = env.get_state().cpu().numpy()
+        L = ni._lib
+        sp = oracle.spec(name)
+        for lo in (0, B - 64):
+            acts = ring[:, :, lo:lo + 64].permute(0, 2, 1).contiguous().cpu().numpy()
+            state = np.stack([oracle.reset(name, oracle.gen_reset_noise(name, seed, lo + i, 0), flavor=oracle.MATH_POLY)[0] for i in range(64)])
+            step = np.zeros(64, dtype=np.int32)
+            for k in range(T):
+                t = k + 1
+                noise = np.stack([oracle.gen_step_noise(name, seed, lo + i, t) for i in range(64)])
+                r = oracle.step(name, state, acts[k], noise, step, max_steps=23, flavor=oracle.MATH_POLY)
+                row = obs[k, lo:lo + 64].cpu().numpy()
+                assert np.array_equal(row.view(np.uint32), r["state_next"].view(np.uint32)), (lo, k)
+                assert np.array_equal(rew[k, lo:lo + 64].cpu().numpy(), r["reward"].astype(np.float32)), (lo, k)
+                f = fl[k, lo:lo + 64].cpu().numpy()
+                assert np.array_equal((f & L.FLAG_TERMINATED) != 0, r["terminated"] != 0) and np.array_equal((f & L.FLAG_TRUNCATED) != 0, r["truncated"] != 0)
+                state, step = r["state_next"].copy(), step + 1
+                for i in np.nonzero((r["terminated"] | r["truncated"]) != 0)[0]:
+                    state[i] = oracle.reset(name, oracle.gen_reset_noise(name, seed, lo + i, t), flavor=oracle.MATH_POLY)[0]
+                    step[i] = 0
+            assert np.array_equal(final[lo:lo + 64].view(np.uint32), state.view(np.uint32)), lo
+        env.close()
+    finally:
+        ni.tune(split_blocks=before)
