@@ -2,6 +2,8 @@
 // The per-environment kernels are instantiated in env_*.hip and reached through nig::EnvLaunch.
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include "nig_kernels.hpp"
 
 namespace nig {
@@ -127,6 +129,7 @@ using namespace nig;
 struct nig_handle {
     int env;
     int device;
+    unsigned cus;          // compute units of `device`: default of the kernel-form thresholds (nig_tune)
     int64_t B;
     uint64_t seed, env0;
     int max_steps;
@@ -215,6 +218,7 @@ static const EnvLaunch *launch_of(int env)
 
 // SafetyMetrics.total_constraints of this handle: built-in constraints still enabled (base.py:115,224-228)
 static int enabled_constraints(const nig_handle *h);
+namespace nig { unsigned split_blocks_for(unsigned cus); unsigned wide_min_blocks_for(unsigned cus); }
 
 static StepArgs base_step_args(const nig_handle *h)
 {
@@ -227,6 +231,7 @@ static StepArgs base_step_args(const nig_handle *h)
     a.tally = L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr;
     a.ld = (uint32_t)L.ld; a.B = (uint32_t)h->B;
     a.env0 = h->env0; a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
+    a.split_blocks = nig::split_blocks_for(h->cus); a.wide_min_blocks = nig::wide_min_blocks_for(h->cus);
     a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.cmask = h->cmask;
     a.hflags = h->flags | (h->may_hold_done ? HF_MAY_HOLD_DONE : 0u);
     a.n_en = enabled_constraints(h);
@@ -244,27 +249,29 @@ static void dispatch_step(const nig_handle *h, const StepArgs &a, bool parity, h
 }
 
 namespace nig {
-// Largest batch, in 256-lane blocks, that runs in the three-wave form.  Default: one block per compute unit of the
-// device the first handle was created on (256 on an MI355X in SPX mode); NIG_SPLIT_BLOCKS / nig_tune override it.
-static bool g_split_explicit = false;
-unsigned g_split_blocks = [] {
-    const char *e = getenv("NIG_SPLIT_BLOCKS");
-    if (e) g_split_explicit = true;
-    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
-}();
-// Smallest batch, in wide (512-lane) blocks, that runs the wide rollout form (envs with WIDE_ROLLOUT_BLOCK): default
-// one wide block per compute unit -- below that 256-lane blocks put the batch on more CUs.  NIG_WIDE_MIN_BLOCKS / nig_tune.
-unsigned g_wide_min_blocks = [] {
-    const char *e = getenv("NIG_WIDE_MIN_BLOCKS");
-    return e ? (unsigned)strtoul(e, nullptr, 10) : 256u;
-}();
-static void split_default_from_device(int device)
+// Kernel-form thresholds (nig_tune).  An explicit setting (environment variable at load, nig_tune later) is
+// process-wide and atomic; without one the threshold is a property of the HANDLE's device -- its compute-unit count,
+// read at nig_create (256 on an MI355X in SPX mode) -- and travels with the launch arguments, so handles on devices
+// with different CU counts (partition modes) or created from several threads never see each other's value
+// (it used to be one plain global set from whichever device came first).
+constexpr unsigned TUNE_UNSET = 0xffffffffu;
+static unsigned tune_from_env(const char *name)
 {
-    static bool done = false;
-    if (done || g_split_explicit) return;
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_split_blocks = (unsigned)cus;
-    done = true;
+    const char *e = getenv(name);
+    return e ? (unsigned)strtoul(e, nullptr, 10) : TUNE_UNSET;
+}
+static std::atomic<unsigned> g_split_override{tune_from_env("NIG_SPLIT_BLOCKS")};      // 256-lane blocks per round of the three-wave form
+static std::atomic<unsigned> g_wide_override{tune_from_env("NIG_WIDE_MIN_BLOCKS")};    // smallest batch, in 512-lane blocks, of the wide form
+static std::atomic<unsigned> g_last_cus{256u};                                         // CU count of the device of the latest handle (reporting only)
+unsigned split_blocks_for(unsigned cus)
+{
+    const unsigned o = g_split_override.load(std::memory_order_relaxed);
+    return o != TUNE_UNSET ? o : cus;
+}
+unsigned wide_min_blocks_for(unsigned cus)
+{
+    const unsigned o = g_wide_override.load(std::memory_order_relaxed);
+    return o != TUNE_UNSET ? o : cus;
 }
 }
 
@@ -275,16 +282,15 @@ const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)
 {
-    if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < 0 || value > 0x7fffffffLL)
+    if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < 0 || value >= (int64_t)nig::TUNE_UNSET)
         return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
-    if (key == NIG_TUNE_WIDE_MIN_BLOCKS) { nig::g_wide_min_blocks = (unsigned)value; return NIG_OK; }
-    nig::g_split_blocks = (unsigned)value;
-    nig::g_split_explicit = true;
+    (key == NIG_TUNE_WIDE_MIN_BLOCKS ? nig::g_wide_override : nig::g_split_override).store((unsigned)value, std::memory_order_relaxed);
     return NIG_OK;
 }
 int64_t nig_tune_get(int32_t key)
 {
-    return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::g_split_blocks : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::g_wide_min_blocks : -1;
+    const unsigned cus = nig::g_last_cus.load(std::memory_order_relaxed);
+    return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::split_blocks_for(cus) : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::wide_min_blocks_for(cus) : -1;
 }
 
 int nig_env_id(const char *name)
@@ -353,11 +359,13 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device < 0 || device >= ndev) return fail(NIG_ERR_INVALID, "nig_create: device index out of range%s");
     HIP_TRY(hipSetDevice(device));
-    split_default_from_device(device);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    nig::g_last_cus.store((unsigned)cus, std::memory_order_relaxed);
 
     nig_handle *h = new (std::nothrow) nig_handle();
     if (!h) return fail(NIG_ERR_INVALID, "nig_create: out of host memory%s");
-    h->env = env; h->device = device; h->B = batch; h->seed = seed; h->env0 = env_index0;
+    h->env = env; h->device = device; h->B = batch; h->seed = seed; h->env0 = env_index0; h->cus = (unsigned)cus;
     h->max_steps = max_episode_steps ? max_episode_steps : SPECS[env].max_episode_steps;
     h->dt = (dt != 0.0) ? dt : SPECS[env].dt;
     h->flags = flags; h->t = 0; h->cmask = 0xFu;

@@ -65,6 +65,8 @@ struct StepArgs {
     const uint32_t *t_ptr; uint32_t t_off;   // launch counter t = (t_ptr ? *t_ptr : 0) + t_off (graph replay keeps t on the device)
     int max_steps; float dt32; double dt; uint32_t hflags; uint32_t cmask;
     int n_en;                         // enabled built-in constraints = SafetyMetrics.total_constraints of every step (base.py:115)
+    // host side only (which kernel form a launch takes, nig_tune): thresholds in effect for this handle's device
+    uint32_t split_blocks, wide_min_blocks;
 };
 // internal bit of StepArgs::hflags (above the public NIG_F_* bits): some lane of the handle may hold
 // NIG_CTR_DONE although the handle auto-resets (never reset, left out by reset(mask), set by
@@ -891,12 +893,6 @@ __global__ void __launch_bounds__(BLK, (BLK / 256) * Env::WIDE_ROLLOUT_WAVES) ro
 }  // namespace nig
 #include "nig_split.hpp"
 namespace nig {
-// Largest batch (in 256-lane blocks) the three-wave forms are used for (nig_tune(NIG_TUNE_SPLIT_BLOCKS); nig_api.hip).
-extern unsigned g_split_blocks;
-// Smallest batch (in wide blocks) the wide rollout form is used for (nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS); nig_api.hip):
-// below it the 256-lane blocks spread a small batch over more CUs.
-extern unsigned g_wide_min_blocks;
-
 // Mixed-batch launch (nig_mixed.hip): per-segment rollout arguments + the block -> segment table, in launch order.
 constexpr int MIXED_MAX_SEG = NIG_MIXED_MAX_SEGMENTS;
 struct MixedArgs {
@@ -1630,8 +1626,9 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
         // the rounds come out even -- measured at 2, 3, 4, 8 and 16 rounds, profiles/r02/rounds_probe.txt -- and loses
         // when the last round is mostly empty (1.5 rounds: -8 %): used when the last round is at least 3/4 full.
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        const unsigned last_round = g_split_blocks ? n_full % g_split_blocks : 0u;
-        const bool even_rounds = g_split_blocks != 0 && (n_full <= g_split_blocks || last_round == 0 || 4u * last_round >= 3u * g_split_blocks);
+        const unsigned per_round = q.s.split_blocks;       // nig_tune(NIG_TUNE_SPLIT_BLOCKS), default: the device's compute units
+        const unsigned last_round = per_round ? n_full % per_round : 0u;
+        const bool even_rounds = per_round != 0 && (n_full <= per_round || last_round == 0 || 4u * last_round >= 3u * per_round);
         if (plain && n_full > 0 && even_rounds) {
             r.block0 = 0;
             launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
@@ -1644,7 +1641,7 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
         constexpr int WB = wide_rollout<Env>::value;
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
         const unsigned n_wide = q.s.B / WB;
-        if (plain && n_wide >= g_wide_min_blocks) {
+        if (plain && n_wide >= q.s.wide_min_blocks) {
             r.block0 = 0;
             switch (out_mode) {
             case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
@@ -1683,7 +1680,7 @@ static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
     if constexpr (split_rollout<Env>::value) {
         // batches that leave one wave per SIMD: producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp)
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        if (plain && q.s.B % BLOCK == 0 && q.s.B / BLOCK <= g_split_blocks) {
+        if (plain && q.s.B % BLOCK == 0 && q.s.B / BLOCK <= q.s.split_blocks) {
             hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(q.s.B / BLOCK), dim3(192 * (BLOCK / 64)), 0, st, q);
             return;
         }

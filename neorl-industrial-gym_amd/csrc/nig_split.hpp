@@ -50,6 +50,20 @@ struct SplitLds {
     static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
 
+// ASSUMPTION the rings rest on: the data slots are written and read with plain LDS accesses and ordered
+// against the counter only by (a) the hardware rule that the DS operations of ONE wave execute in issue order on
+// gfx950's LDS pipeline -- so "write data, then write counter" and "read counter, then read data" need no wait in
+// between -- and (b) wavefront-scope fences that pin the COMPILER's order of those accesses.  Under the HIP / LLVM
+// memory model the slots are formally racing (the fences are not workgroup-scope release / acquire); a workgroup-scope
+// fence would insert an s_waitcnt lgkmcnt(0) per post and per wait, i.e. on the integrator's critical path.  The rule
+// holds for this target only (not in threadgroup-split mode, not necessarily on another architecture), hence:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "nig_split.hpp relies on in-order LDS execution within a wave as implemented on gfx950; re-validate before building for another target"
+#endif
+// tests/test_gpu_split.py + tests/test_gpu_round3.py::test_three_wave_form_rows_against_oracle_trajectories would show a
+// reordering as a bit mismatch (the spin loops could also hang: they carry no timeout on purpose -- a rollout of 10^5
+// steps is legitimate -- so a toolchain change must be re-validated with those tests under a `timeout`).
+//
 // The ring counters are accessed through LDS-address-space pointers: a volatile access through a generic pointer
 // is compiled to a system-coherent FLAT operation with a vmcnt(0) wait behind it.
 using lds_u32_t = __attribute__((address_space(3))) uint32_t;
