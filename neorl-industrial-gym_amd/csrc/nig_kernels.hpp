@@ -916,6 +916,7 @@ struct PolicyArgs {
     uint32_t out_stride;
     float *obs_out; uint64_t obs_step_stride;                        // row-major [B][S] per step, pre-step obs
     float *act_out; uint32_t ld_act_out; uint64_t act_step_stride;   // [A][ld] per step
+    uint32_t block0;            // first 256-lane block of this launch (whole blocks and a ragged last block are separate launches)
 };
 
 // The policy's random draws of one step: they depend on the lane's key only, not on the observation, so the
@@ -1138,7 +1139,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
     const nig_policy *pol = &s_pol;
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
-    const uint32_t base = blockIdx.x * BLOCK;
+    const uint32_t base = (blockIdx.x + q.block0) * BLOCK;
     const bool in_range = base + tid < p.B;
     if constexpr (COOP) {
         if (base + (tid & ~63u) >= p.B) return;    // a partial wave keeps all 64 lanes: they are the reset's workers
@@ -1678,10 +1679,19 @@ template <class Env>
 static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
 {
     if constexpr (split_rollout<Env>::value) {
-        // batches that leave one wave per SIMD: producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp)
+        // Producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp) for the batch's whole 256-lane blocks --
+        // up to one block per CU, and larger batches in rounds under the rule of the open-loop rollout (the last round at
+        // least 3/4 full) -- and the one-wave kernel for a ragged last block.  (Round 2 sent a batch with a ragged tail,
+        // or of more than one round, to the one-wave kernel whole.)
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        if (plain && q.s.B % BLOCK == 0 && q.s.B / BLOCK <= q.s.split_blocks) {
-            hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(q.s.B / BLOCK), dim3(192 * (BLOCK / 64)), 0, st, q);
+        const unsigned n_full = q.s.B / BLOCK, per_round = q.s.split_blocks;
+        const unsigned last_round = per_round ? n_full % per_round : 0u;
+        const bool even_rounds = per_round != 0 && (n_full <= per_round || last_round == 0 || 4u * last_round >= 3u * per_round);
+        if (plain && n_full > 0 && even_rounds) {
+            PolicyArgs r = q;
+            r.block0 = 0;
+            hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(n_full), dim3(192 * (BLOCK / 64)), 0, st, r);
+            if (q.s.B % BLOCK) { r.block0 = n_full; hipLaunchKernelGGL((rollout_policy_kernel<Env>), dim3(1), dim3(BLOCK), 0, st, r); }
             return;
         }
     }

@@ -114,7 +114,8 @@ def test_split_form_handle_variants(ni, kw):
 
 def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
     """Closed-loop rollouts (nig_rollout_policy) through one handle; returns every observable as CPU tensors."""
-    ni.tune(split_blocks=256 if split else 0)
+    if split is not None:                      # None: keep the knob the caller set
+        ni.tune(split_blocks=256 if split else 0)
     env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
     env.set_policy(policy)
     env.reset()
@@ -154,6 +155,20 @@ def test_split_policy_form_equals_one_wave_form(ni, which, stream):
 
 
 @pytest.mark.parametrize("max_steps", [1, 2, 3])
+@pytest.mark.parametrize("B,split_blocks", [(1024 + 100, 256), (256 + 1, 256), (5 * 256, 2), (8 * 256 + 77, 4), (7 * 256, 4)])
+def test_split_policy_form_with_a_ragged_tail_and_in_rounds(ni, B, split_blocks):
+    """Round 3: the closed loop's whole 256-lane blocks run the three-wave form and a ragged last block the one-wave
+    kernel (one call, two launches); batches of several rounds (here: rounds of 2 or 4 blocks) run it in rounds when the
+    last round is at least 3/4 full ((5 blocks, 2 per round) and (7, 4): yes; (8 + tail, 4): even) -- all bit-identical
+    to the one-wave kernel, PID memory and transition stream included."""
+    for policy in (ni.behaviour_policy(NAME, "medium"), ni.pid_agent(12, 3)):
+        kw = dict(policy=policy, B=B, chunks=[7, 6], stream="transitions", max_steps=9)
+        ni.tune(split_blocks=split_blocks)
+        a = _run_policy(ni, None, **kw)
+        b = _run_policy(ni, False, **kw)
+        _same(a, b)
+
+
 def test_split_form_resets_every_step(ni, max_steps):
     """Episodes of one to three steps: every lane (or half / a third of them) is renewed by the cooperative reset
     in every step, the integrator's heaviest path, while producer and recorder keep running ahead / behind."""
