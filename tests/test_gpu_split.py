@@ -154,7 +154,6 @@ def test_split_policy_form_equals_one_wave_form(ni, which, stream):
     _same(a, b)
 
 
-@pytest.mark.parametrize("max_steps", [1, 2, 3])
 @pytest.mark.parametrize("B,split_blocks", [(1024 + 100, 256), (256 + 1, 256), (5 * 256, 2), (8 * 256 + 77, 4), (7 * 256, 4)])
 def test_split_policy_form_with_a_ragged_tail_and_in_rounds(ni, B, split_blocks):
     """Round 3: the closed loop's whole 256-lane blocks run the three-wave form and a ragged last block the one-wave
@@ -169,6 +168,7 @@ def test_split_policy_form_with_a_ragged_tail_and_in_rounds(ni, B, split_blocks)
         _same(a, b)
 
 
+@pytest.mark.parametrize("max_steps", [1, 2, 3])
 def test_split_form_resets_every_step(ni, max_steps):
     """Episodes of one to three steps: every lane (or half / a third of them) is renewed by the cooperative reset
     in every step, the integrator's heaviest path, while producer and recorder keep running ahead / behind."""
