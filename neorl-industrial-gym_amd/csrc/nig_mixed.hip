@@ -43,25 +43,32 @@ __global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs
         if (j < m.n_seg && blockIdx.x >= m.blk_end[j - 1]) { q = m.seg[j]; env = m.env[j]; blk0 = m.blk_end[j - 1]; }
     }
     const uint32_t base = (blockIdx.x - blk0) * BLOCK;         // first lane of the block inside its segment
-    // unpaired form for ChemicalReactor (its launch-counter parity is per handle), predicated lanes (ragged segments)
+    // A WHOLE block of a handle on which no lane can be frozen runs the unpredicated body without freeze handling (FULL,
+    // NOFREEZE: counted vmcnt waits instead of a drain per step, no second copy of the state -- what the stand-alone
+    // kernels' whole blocks run); a segment's ragged last block, or a handle with frozen lanes, the predicated one.
+    // ChemicalReactor stays unpaired (its launch-counter parity is per handle).
+    const bool lean = base + BLOCK <= q.s.B && (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+#define NIG_MIXED_BODY(Env)                                                   \
+    if (lean) rollout_body<Env, OUT, false, true, true>(q, base, smem);        \
+    else rollout_body<Env, OUT, false, false>(q, base, smem);                  \
+    break
     switch (env) {
-    case NIG_ENV_CHEMICAL_REACTOR: rollout_body<ChemicalReactor, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_CHEMICAL_REACTOR: NIG_MIXED_BODY(ChemicalReactor);
     case NIG_ENV_POWER_GRID:
-        // whole blocks of a handle on which no lane can be frozen: the LDS-resident body (nig_pg_lds.hpp; ~110 registers,
-        // where the register-resident one spilled ~70 dwords under this kernel's 168) -- bit-identical, tests/test_gpu_mixed.py
-        if (base + BLOCK <= q.s.B && (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0)
-            pg_lds_rollout_body<OUT, BLOCK>(q, base, smem);
-        else
-            rollout_body<PowerGrid, OUT, false, false>(q, base, smem);
+        // whole blocks: the LDS-resident body (nig_pg_lds.hpp; ~110 registers, where the register-resident one spilled ~70
+        // dwords under this kernel's 168) -- bit-identical, tests/test_gpu_mixed.py
+        if (lean) pg_lds_rollout_body<OUT, BLOCK>(q, base, smem);
+        else rollout_body<PowerGrid, OUT, false, false>(q, base, smem);
         break;
-    case NIG_ENV_ROBOT_ASSEMBLY: rollout_body<RobotAssembly, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_ADV_CHEMICAL_REACTOR: rollout_body<AdvancedChemicalReactor, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_ADV_POWER_GRID: rollout_body<AdvancedPowerGrid, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_HVAC_CONTROL: rollout_body<HVACControl, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_WATER_TREATMENT: rollout_body<WaterTreatment, OUT, false, false>(q, base, smem); break;
-    case NIG_ENV_STEEL_ANNEALING: rollout_body<SteelAnnealing, OUT, false, false>(q, base, smem); break;
-    default: rollout_body<SupplyChain, OUT, false, false>(q, base, smem); break;
+    case NIG_ENV_ROBOT_ASSEMBLY: NIG_MIXED_BODY(RobotAssembly);
+    case NIG_ENV_ADV_CHEMICAL_REACTOR: NIG_MIXED_BODY(AdvancedChemicalReactor);
+    case NIG_ENV_ADV_POWER_GRID: NIG_MIXED_BODY(AdvancedPowerGrid);
+    case NIG_ENV_HVAC_CONTROL: NIG_MIXED_BODY(HVACControl);
+    case NIG_ENV_WATER_TREATMENT: NIG_MIXED_BODY(WaterTreatment);
+    case NIG_ENV_STEEL_ANNEALING: NIG_MIXED_BODY(SteelAnnealing);
+    default: NIG_MIXED_BODY(SupplyChain);
     }
+#undef NIG_MIXED_BODY
 }
 
 }  // namespace nig

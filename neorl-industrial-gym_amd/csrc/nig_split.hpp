@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         // ------------------------------------------------------------------ producer
         const uint64_t gi = p.env0 + (uint64_t)(base + lane);
         const float *ring = p.actions + base;
-        constexpr int LA = 4;                                  // actions are loaded LA steps before they are handed on
+#ifndef NIG_SPLIT_LA
+#define NIG_SPLIT_LA 4
+#endif
+        constexpr int LA = NIG_SPLIT_LA;                       // actions are loaded LA steps before they are handed on
         float buf[LA][A];
         uint32_t kept0 = 0u, kept1 = 0u;                       // words 2-3 of the current pair's Philox block
         int aslot = q.it0 % q.ring_len;                        // ring slot of the action loaded next
@@ -231,16 +234,30 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             load_action(ab);                      // this register set's next use: local step j + LA
             pslot = (pslot + 1 == K) ? 0 : pslot + 1;
         };
-        static_assert(LA == 4, "the loop below is written out for this depth");
-        using r0 = std::integral_constant<int, 0>; using r1 = std::integral_constant<int, 1>;
-        using r2 = std::integral_constant<int, 2>; using r3 = std::integral_constant<int, 3>;
+        // the loop is unrolled LA times so that every action register set and the position in the pair of launch counters
+        // are compile-time (LA even)
+        static_assert(LA % 2 == 0 && LA >= 2 && LA <= 8, "unrolled below for even depths up to 8");
 #pragma unroll
         for (int j = 0; j < LA; ++j) load_action(buf[j]);
+        auto produce_k = [&](auto k_tag, const int j0) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            if constexpr (k < LA) produce(std::integral_constant<int, k>{}, j0 + k);
+        };
         int j = 0;
-        for (; j + LA <= n; j += LA) { produce(r0{}, j); produce(r1{}, j + 1); produce(r2{}, j + 2); produce(r3{}, j + 3); }
-        if (j < n) produce(r0{}, j);
-        if (j + 1 < n) produce(r1{}, j + 1);
-        if (j + 2 < n) produce(r2{}, j + 2);
+        for (; j + LA <= n; j += LA) {
+            produce_k(std::integral_constant<int, 0>{}, j); produce_k(std::integral_constant<int, 1>{}, j);
+            produce_k(std::integral_constant<int, 2>{}, j); produce_k(std::integral_constant<int, 3>{}, j);
+            produce_k(std::integral_constant<int, 4>{}, j); produce_k(std::integral_constant<int, 5>{}, j);
+            produce_k(std::integral_constant<int, 6>{}, j); produce_k(std::integral_constant<int, 7>{}, j);
+        }
+        // tail: at most LA - 1 steps
+        auto tail_k = [&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            if constexpr (k < LA - 1) { if (j + k < n) produce(std::integral_constant<int, k>{}, j + k); }
+        };
+        tail_k(std::integral_constant<int, 0>{}); tail_k(std::integral_constant<int, 1>{}); tail_k(std::integral_constant<int, 2>{});
+        tail_k(std::integral_constant<int, 3>{}); tail_k(std::integral_constant<int, 4>{}); tail_k(std::integral_constant<int, 5>{});
+        tail_k(std::integral_constant<int, 6>{});
         return;
     }
 
