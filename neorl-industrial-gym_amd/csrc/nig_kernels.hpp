@@ -221,6 +221,39 @@ __device__ __forceinline__ void flush_tally(double *T, uint32_t ld, double ret, 
     for (int r = 0; r < NIG_T_ROWS; ++r) T[(size_t)r * ld] = v[r];
 }
 
+// The same bookkeeping as no-return float64 atomics into the lane's own column (global_atomic_add / min / max_f64,
+// executed at the memory side): nothing is loaded, nothing is waited for.  The step kernel used flush_tally, i.e. 13
+// loads, a wait and 13 stores behind the step of every finishing lane -- a third dependent memory round trip on the
+// critical path of a launch that is latency-bound at the headline batch (profiles/r03/step_api_probe.py: the tally cost
+// 0.8 us of a 5.1 us launch).  Each row is one IEEE operation on the same operands as in flush_tally, and a lane's column
+// is touched by that lane only (a kernel boundary orders consecutive steps), so the rows hold the same bits.
+__device__ __forceinline__ void flush_tally_atomic(double *T, uint32_t ld, double ret, int step, uint32_t viol_ep, int ncrit, int n_en)
+{
+    typedef __attribute__((address_space(1))) double gdouble;
+    auto add = [&](int r, double x) { (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble *)(T + (size_t)r * ld), x); };
+    const double len = (double)step;
+    add(NIG_T_EPISODES, 1.0);
+    add(NIG_T_RET_SUM, ret);
+    add(NIG_T_RET_SQ, ret * ret);
+    (void)__builtin_amdgcn_global_atomic_fmin_f64((gdouble *)(T + (size_t)NIG_T_RET_MIN * ld), ret);
+    (void)__builtin_amdgcn_global_atomic_fmax_f64((gdouble *)(T + (size_t)NIG_T_RET_MAX * ld), ret);
+    add(NIG_T_LEN_SUM, len);
+    add(NIG_T_LEN_SQ, len * len);
+    add(NIG_T_VIOL, (double)viol_ep);
+    add(NIG_T_CRIT, (double)ncrit);
+    add(NIG_T_SHUTDOWN, (ncrit > 0) ? 1.0 : 0.0);
+    add(NIG_T_SUCCESS, (ret > 0.0) ? 1.0 : 0.0);
+    add(NIG_T_SATISFIED, (double)(n_en * step - (int)viol_ep));
+    add(NIG_T_CONSTRAINTS, (double)(n_en * step));
+}
+
+// Which of the two the step kernel uses: the atomics unless the env says otherwise.  They execute at the memory side at
+// ~1.3 TB/s chip-wide (MI355X_MICROARCH.md "Global float atomics"): nothing for an env whose lanes finish rarely
+// (ChemicalReactor 0.3 % per step, RobotAssembly 2.4 %), but PowerGrid finishes 18 % of its lanes every step -- 19 bytes
+// of atomic traffic per env-step, ~16 % of its step launch at 262 144 lanes -- so it keeps the load / store flush.
+template <class E, class = void> struct tally_atomic : std::true_type {};
+template <class E> struct tally_atomic<E, std::void_t<decltype(E::TALLY_ATOMIC)>> : std::bool_constant<E::TALLY_ATOMIC> {};
+
 // Register-resident partial tally of one lane for the duration of a fused rollout.
 struct LaneTally {
     double ret_sum, ret_sq, ret_min, ret_max, len_sq;
@@ -403,7 +436,11 @@ __global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVE
         }
         if (done) {
             (p.life_viol + base)[tid] += (long long)viol_ep;   // base.py:183 total_violations (never reset)
-            if (p.tally) { flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en); ret = 0.0; }
+            if (p.tally) {
+                if constexpr (tally_atomic<Env>::value) flush_tally_atomic(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en);
+                else flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en);
+                ret = 0.0;
+            }
             if (p.final_obs) {
                 float *fo = p.final_obs + base;
 #pragma unroll
