@@ -214,11 +214,13 @@ struct u32x4 { uint32_t x, y, z, w; };
 // then folds multiply and add into v_mad_u64_u32 ITSELF.  Rounds 1-2 had the instruction as inline asm, and hipcc's
 // hazard recognizer, blind to what an asm statement is, put an s_nop behind almost every one of them: 70 of
 // PowerGrid's ~1 250 issue slots per step.  The asm below has no inputs and no side effects: identical copies are
-// merged and hoisted, one s_mov_b64 per kernel.
+// merged and hoisted, one v_mov_b64 per kernel.  The zero lives in a VECTOR register pair on purpose: the multiplier is a
+// literal / SGPR, and gfx950 lets a VALU instruction read only one scalar source -- with the zero in an SGPR pair hipcc
+// re-materialised it into a VGPR pair before almost every multiply (34 v_mov_b64 per PowerGrid step).
 __device__ __forceinline__ uint64_t opaque_zero64()
 {
     uint64_t z;
-    asm("s_mov_b64 %0, 0" : "=s"(z));
+    asm("v_mov_b64 %0, 0" : "=v"(z));
     return z;
 }
 __device__ __forceinline__ void mulhilo32(uint32_t m, uint32_t x, uint32_t &hi, uint32_t &lo)

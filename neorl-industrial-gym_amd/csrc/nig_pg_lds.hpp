@@ -255,6 +255,9 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
 #ifdef NIG_DIAG_PG_NOSTORE             // (diagnostic: the reads without the stores)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(v[j]));
+#elif defined(NIG_DIAG_PG_PLAINSTORE)   // (diagnostic: ordinary instead of streaming stores for the trajectory rows)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) oo[lane + 64u * j] = v[j];
 #else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, v[j]);
