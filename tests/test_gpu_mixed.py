@@ -189,14 +189,23 @@ def test_rollout_mixed_over_caller_owned_handles(ni):
         a.fill_actions(40 + s, ring[s])
     ra, fa = (torch.zeros(T, a.ld, dtype=torch.float32, device=a.device), torch.zeros(T, a.ld, dtype=torch.int32, device=a.device))
     rb, fb = torch.zeros_like(ra), torch.zeros_like(fa)
+    oa = torch.full((T, a.S_max, a.ld), float("nan"), dtype=torch.float32, device=a.device)     # observation rows of every step
+    ob = torch.full_like(oa, float("nan"))
     a.reset(); b.reset()
-    a.rollout(T, ring, ra, fa); b.rollout(T, ring, rb, fb)
+    a.rollout(T, ring, ra, fa, oa); b.rollout(T, ring, rb, fb, ob)
     a.rollout(7, ring); b.rollout(7, ring)                      # output-free form, odd length
+    a.rollout(5, ring, ra[:5], fa[:5]); b.rollout(5, ring, rb[:5], fb[:5])      # reward + flags only
     torch.cuda.synchronize()
     assert torch.equal(a.state_soa.view(torch.int32), b.state_soa.view(torch.int32))
     assert torch.equal(ra, rb) and torch.equal(fa, fb)
+    # ragged segments: whole blocks run the unpredicated bodies (PowerGrid the LDS-resident one), the last block of a
+    # segment the predicated one; rows >= S of a segment, padding columns and rows of other segments stay untouched (NaN)
+    assert torch.equal(oa.view(torch.int32), ob.view(torch.int32))
+    for env, o in zip(a.envs, a.offsets):
+        assert not bool(torch.isnan(oa[:, :env.state_dim, o:o + env.batch]).any())
+        assert bool(torch.isnan(oa[:, env.state_dim:, o:o + env.batch]).all()) or env.state_dim == a.S_max
     for x, y in zip(a.envs, b.envs):
-        assert torch.equal(x.ctr, y.ctr) and torch.equal(x.tally, y.tally) and x.counter == y.counter == T + 7
+        assert torch.equal(x.ctr, y.ctr) and torch.equal(x.tally, y.tally) and x.counter == y.counter == T + 7 + 5
     a.close(); b.close()
 
 
