@@ -668,7 +668,12 @@ def measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, B, K, W,
         mix.fill_actions(1000 + s, ring[s])
     rew = torch.empty(P, mix.ld, dtype=torch.float32, device=device)
     fl = torch.empty(P, mix.ld, dtype=torch.int32, device=device)
-    obs = torch.empty(P, mix.S_max, mix.ld, dtype=torch.float32, device=device) if full else None
+    obs = None
+    if full:
+        try:    # 33.5 GB at the default size (250 steps x 32 rows x 1 048 576 lanes): fall back to reward + flags if it does not fit
+            obs = torch.empty(P, mix.S_max, mix.ld, dtype=torch.float32, device=device)
+        except torch.cuda.OutOfMemoryError:
+            full = False
     mix.reset()
 
     class _W:
@@ -703,7 +708,7 @@ def measure_mixed(args, ni, torch, dist, device, comm_dev, world, rank, B, K, W,
                                   + ("ONE fused launch over all segments" if fused else "one launch per segment on 7 streams")
                                   + (", outputs: observation rows [T][S_max][ld] + reward + flags" if full else ", reward+flags outputs"),
                       "batch_per_gpu": B, "plan_steps": P, "env_steps_per_step": P * B * world, "segments": counts,
-                      "launch": args.mixed_launch, "outputs": args.mixed_outputs},
+                      "launch": args.mixed_launch, "outputs": "full" if full else "min"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel": ("mixed_rollout_kernel<%d>" % out_mode) if fused else "rollout_kernel<*,%d> x7 (concurrent streams)" % out_mode,

@@ -164,7 +164,10 @@ int nig_layout_query(int env, int64_t batch, uint32_t flags, nig_layout *out);
  *                      (chemical_reactor.py:62-69 hard-codes 500 / 0.1), here it is honoured
  *   dt                 0 = default
  *   workspace          device memory of nig_layout.bytes (256-byte aligned) owned by the
- *                      caller, or NULL to let the library hipMalloc it
+ *                      caller, or NULL to let the library hipMalloc it.  It must be ordinary
+ *                      device-local memory of `device` (hipMalloc / a torch CUDA tensor), not
+ *                      host-pinned or fine-grained memory: with NIG_F_TALLY the step kernel
+ *                      updates the episode tally with float64 hardware atomics
  * States are undefined until nig_reset.
  */
 int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_index0,
