@@ -240,10 +240,12 @@ def rollout_kernel_name(wl):
     last = blocks % per_round if per_round else 0
     if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):   # (+ a one-wave launch for a ragged last block)
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
-    # PowerGrid: whole 512-lane blocks of a batch of at least nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS) of them run the
-    # LDS-resident wide form (csrc/nig_pg_lds.hpp); the rest of the batch (< 512 lanes) the register-resident kernel
-    if wl.key == "pg" and wl.B // 512 >= max(1, wl.ni.tune()["wide_min_blocks"]):
-        return "rollout_wide_kernel<PowerGrid,%d,512>" % out
+    # PowerGrid: the LDS-resident body (csrc/nig_pg_lds.hpp) -- whole 512-lane blocks of a batch of at least
+    # nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS) of them in the wide form, whole 256-lane blocks otherwise; a ragged tail (and
+    # everything, with the knob at 2^30 or more) on the register-resident kernel
+    wide_min = wl.ni.tune()["wide_min_blocks"]
+    if wl.key == "pg" and wide_min < (1 << 30) and wl.B >= 256:
+        return "rollout_wide_kernel<PowerGrid,%d,%d>" % (out, 512 if (wl.B // 512 >= max(1, wide_min)) else 256)
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 
 

@@ -141,7 +141,8 @@ const char *nig_last_error(void);
  *   NIG_TUNE_WIDE_MIN_BLOCKS  smallest batch, in 512-lane blocks, that nig_rollout runs in the WIDE form (csrc/nig_kernels.hpp
  *                           rollout_wide_kernel: PowerGrid / RobotAssembly, 512-thread blocks at four waves per SIMD,
  *                           handles on which no lane can be frozen); default = the compute units of the handle's
- *                           device (one wide block per compute unit), a huge value = never.  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.
+ *                           device (one wide block per compute unit); smaller batches run the same LDS-resident
+ *                           body in 256-lane blocks; 2^30 or more = never use that body (rollout_kernel only).  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
 enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1 };
 int nig_tune(int32_t key, int64_t value);

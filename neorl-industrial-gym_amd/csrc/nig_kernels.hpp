@@ -1676,18 +1676,38 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
     }
     unsigned first = 0;                            // first 256-lane block the forms below still have to run
     if constexpr (!PAIRED && wide_rollout<Env>::value != 0) {
+        // Envs with an LDS-resident rollout body (PowerGrid, nig_pg_lds.hpp), handles on which no lane can be frozen:
+        // from nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS) wide blocks up, the batch's whole 512-lane blocks in the wide form
+        // (four waves per SIMD); a remaining whole 256-lane block, and every whole block of a smaller batch, in the same
+        // body with 256-thread blocks (three blocks per CU by LDS: 262 144 lanes would need 1.33 rounds, which is why
+        // big batches take the wide form; small ones spread over more CUs this way and still run ~7 % fewer instructions
+        // than the register-resident kernel, without its spills: 65 536 lanes 927 -> 858 us, 98 304 lanes 1.29 -> 1.08 ms
+        // per 250 steps, profiles/r03/pg_small.txt).  A knob value of 2^30 or more keeps everything on rollout_kernel.
         constexpr int WB = wide_rollout<Env>::value;
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
-        const unsigned n_wide = q.s.B / WB;
-        if (plain && n_wide >= q.s.wide_min_blocks) {
-            r.block0 = 0;
-            switch (out_mode) {
-            case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
-            case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
-            case 2: hipLaunchKernelGGL((rollout_wide_kernel<Env, 2, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
-            default: hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+        if (plain && q.s.wide_min_blocks < (1u << 30)) {
+            const unsigned n_wide = q.s.B / WB;
+            if (n_wide > 0 && n_wide >= q.s.wide_min_blocks) {
+                r.block0 = 0;
+                switch (out_mode) {
+                case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+                case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+                case 2: hipLaunchKernelGGL((rollout_wide_kernel<Env, 2, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+                default: hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
+                }
+                first = n_wide * (WB / BLOCK);
             }
-            first = n_wide * (WB / BLOCK);
+            if (n_full > first) {
+                r.block0 = first;
+                const unsigned nb = n_full - first;
+                switch (out_mode) {
+                case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
+                case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
+                case 2: hipLaunchKernelGGL((rollout_wide_kernel<Env, 2, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
+                default: hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
+                }
+                first = n_full;
+            }
         }
     }
     if (n_full > first) { r.block0 = first; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full - first, st); }

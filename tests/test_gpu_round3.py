@@ -56,7 +56,9 @@ def _pg_ring(env, R, t0=70):
 
 
 def _pg_run(ni, wide, B, chunks, outputs, R, max_steps=1000, seed=11, tally=True, env_index0=0, cmask=None, t0=70):
-    ni.tune(wide_min_blocks=1 if wide else NEVER)
+    """wide: True = the LDS-resident body, whole 512-lane blocks in the wide form; an int = the knob value (256: the
+    default -- a small batch then runs the same body in 256-lane blocks); False = rollout_kernel only."""
+    ni.tune(wide_min_blocks=NEVER if wide is False else (1 if wide is True else int(wide)))
     env = ni.make_batched(PG, B, seed=seed, autoreset=True, tally=tally, max_episode_steps=max_steps, env_index0=env_index0)
     if cmask is not None:
         env.set_constraint_mask(cmask)
@@ -103,12 +105,15 @@ def wide_knob(ni):
 
 
 @pytest.mark.parametrize("outputs", ["none", "min", "last", "soa", "aos"])
-def test_pg_lds_rollout_equals_register_rollout(ni, wide_knob, outputs):
-    """Three wide blocks + one whole 256-lane block + a ragged tail: the wide kernel runs the first 1536 lanes, the
-    register kernel the rest; the same batch entirely on the register kernel must agree in every observable, over
-    several launches (ring wrap-around, odd step counts)."""
+@pytest.mark.parametrize("knob", [True, 256])
+def test_pg_lds_rollout_equals_register_rollout(ni, wide_knob, outputs, knob):
+    """Three wide blocks + one whole 256-lane block + a ragged tail.  knob True: the wide (512-lane) form runs the first
+    1536 lanes, the 256-lane form of the same LDS-resident body the next block, rollout_kernel the ragged tail; knob 256
+    (the default): the batch is below the wide threshold, so all seven whole blocks run the 256-lane form.  Either way
+    every observable equals the same batch entirely on the register-resident kernel, over several launches (ring
+    wrap-around, odd step counts)."""
     B = 3 * 512 + 256 + 37
-    a = _pg_run(ni, True, B, [7, 1, 12], outputs, R=5)
+    a = _pg_run(ni, knob, B, [7, 1, 12], outputs, R=5)
     b = _pg_run(ni, False, B, [7, 1, 12], outputs, R=5)
     _same(a, b)
 

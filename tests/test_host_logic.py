@@ -287,7 +287,8 @@ def test_bench_names_the_kernel_the_library_launches():
         assert name("cr", 65536 + 100).startswith("split_")          # whole blocks in this form, the ragged last block in a one-wave launch
         assert name("cr", 200).startswith("rollout_kernel<")          # no whole block at all
         assert name("pg", 262144) == "rollout_wide_kernel<PowerGrid,3,512>"      # >= 256 blocks of 512 lanes: the LDS-resident form
-        assert name("pg", 65536) == "rollout_kernel<PowerGrid,3>"               # 128 wide blocks: below the default threshold
+        assert name("pg", 65536) == "rollout_wide_kernel<PowerGrid,3,256>"      # 128 wide blocks: below the threshold, 256-lane blocks of the same body
+        assert name("pg", 100) == "rollout_kernel<PowerGrid,3>"                 # no whole block
         assert name("ra", 262144) == "rollout_kernel<RobotAssembly,3>"
         ni.tune(split_blocks=0, wide_min_blocks=1 << 30)
         assert name("cr", 65536).startswith("rollout_kernel<") and name("pg", 262144) == "rollout_kernel<PowerGrid,3>"
