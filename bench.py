@@ -363,6 +363,12 @@ def spawn_ranks(n, argv):
     import importlib.util
     import socket
     import subprocess
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    if "rocprof" in preload:
+        # a profiler preload has initialised the GPU in THIS process before main() ran: starting another program from it is
+        # the exec-from-a-GPU-process pattern this pool forbids.  Profile one rank of a launcher-started job instead.
+        raise SystemExit("bench.py: --gpus N > 1 under a profiler preload: start the ranks with torch.distributed.run and "
+                         "profile inside it (or profile a --gpus 1 run); bench.py will not spawn from a GPU-initialised process")
     spec = importlib.util.spec_from_file_location("_nig_build", os.path.join(ROOT, "neorl-industrial-gym_amd", "_build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)

@@ -1,4 +1,7 @@
-"""-m gpu: round-3 additions pinned on the device: bench.py's own N-rank launch with the real workload, ..."""
+"""-m gpu: round-3 additions pinned on the device: bench.py's own N-rank launch with the real workload; PowerGrid's
+LDS-resident rollout (csrc/nig_pg_lds.hpp) against the register-resident kernel and the oracle, up to the maximum batch;
+the reference-side pins of the get_dataset behaviour laws (device policy kernel), ChemicalReactor's info dicts and the
+three-wave rollout directly against oracle trajectories."""
 import json
 import os
 import subprocess
@@ -282,3 +285,33 @@ def test_three_wave_form_rows_against_oracle_trajectories(ni, oracle):
         env.close()
     finally:
         ni.tune(split_blocks=before)
+
+
+def test_pg_lds_rollout_at_the_maximum_batch(ni, wide_knob, oracle):
+    """NIG_MAX_BATCH = 2^24 PowerGrid lanes (32 768 wide blocks; a 2.1 GB state matrix and 2.1 GB of row-major rows per
+    step: every row offset of the LDS-resident kernel at the far end of its range): the first and the last 4 096 lanes
+    equal the oracle bit for bit after three fused steps, the last step's rows equal the final state where no reset fell."""
+    B, T = 1 << 24, 3
+    ni.tune(wide_min_blocks=256)
+    env = ni.make_batched(PG, B, autoreset=True, tally=False)
+    ring = torch.empty(T, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
+    for s in range(T):
+        env.fill_actions(s + 1, ring[s])
+    rew = torch.zeros(env.ld, dtype=torch.float32, device=env.device)
+    fl = torch.zeros(env.ld, dtype=torch.int32, device=env.device)
+    obs = torch.zeros(1, B, env.state_dim, dtype=torch.float32, device=env.device)
+    env.reset()
+    env.rollout(2, ring[0:2], rew, fl)
+    env.rollout(1, ring[2:3], rew, fl, obs)
+    torch.cuda.synchronize()
+    assert env.counter == T
+    for lo in (0, B - 4096):
+        st, sc, _, _ = oracle.rollout("pg", 4096, T, env0=lo, flavor=oracle.MATH_POLY)
+        got = env.state_soa[:, lo:lo + 4096].t().contiguous().cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), st.view(np.uint32)), lo
+        assert np.array_equal(env.current_step[lo:lo + 4096].cpu().numpy(), sc), lo
+        keep = (fl[lo:lo + 4096] & ni._lib.FLAG_DID_RESET) == 0
+        o = obs[0, lo:lo + 4096]
+        assert int(keep.sum()) > 2000
+        assert torch.equal(o[keep].view(torch.int32), env.state_soa[:, lo:lo + 4096].t()[keep].contiguous().view(torch.int32))
+    env.close()

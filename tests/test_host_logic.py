@@ -323,6 +323,13 @@ def test_bench_launches_and_verifies_its_own_ranks():
     assert rec["value"] is None and "rehearsal" in rec          # never mistaken for a measurement
 
 
+def test_bench_does_not_spawn_under_a_profiler_preload():
+    """A rocprofv3 preload initialises the GPU before main(): spawning the ranks from that process would be an exec from a
+    GPU-initialised process (forbidden on this pool) -- bench.py refuses with a message instead."""
+    p, rec = _run_bench(["--gpus", "2"], {"NIG_BENCH_REHEARSE": "cpu", "ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert p.returncode != 0 and rec is None and "profiler preload" in p.stderr
+
+
 def test_bench_refuses_a_world_that_differs_from_gpus():
     """--gpus N under a launcher that formed another world size: non-zero exit, message names the command."""
     p, rec = _run_bench(["--gpus", "2"], {"NIG_BENCH_REHEARSE": "cpu", "WORLD_SIZE": "3", "RANK": "0"})
