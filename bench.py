@@ -233,13 +233,16 @@ def honest_brackets(torch, wl, K, roof, settle_s, idle_gap=1.0):
 
 
 def rollout_kernel_name(wl):
-    """The kernel nig_rollout launches for this workload (csrc/nig_kernels.hpp launch_rollout_form): ChemicalReactor
-    batches of whole 256-lane blocks, up to nig_tune(NIG_TUNE_SPLIT_BLOCKS) of them, run in the three-wave form."""
+    """The kernel nig_rollout launches for this workload (csrc/nig_kernels.hpp launch_rollout_form): ChemicalReactor and
+    RobotAssembly batches of whole 256-lane blocks, up to nig_tune(NIG_TUNE_SPLIT_BLOCKS) of them, run in the three-wave
+    form (ChemicalReactor also larger batches, in rounds of that many blocks)."""
     out = {"none": 0, "min": 1, "full": 3}[wl.outputs]
     blocks, per_round = wl.B // 256, wl.ni.tune()["split_blocks"]
     last = blocks % per_round if per_round else 0
     if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):   # (+ a one-wave launch for a ragged last block)
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
+    if wl.key == "ra" and blocks > 0 and per_round and blocks <= per_round:     # RobotAssembly: the three-wave form for one round only
+        return "split_rollout_kernel<RobotAssembly,%d,4>" % out
     # PowerGrid: the LDS-resident body (csrc/nig_pg_lds.hpp) -- whole 512-lane blocks of a batch of at least
     # nig_tune(NIG_TUNE_WIDE_MIN_BLOCKS) of them in the wide form, whole 256-lane blocks otherwise; a ragged tail (and
     # everything, with the knob at 2^30 or more) on the register-resident kernel

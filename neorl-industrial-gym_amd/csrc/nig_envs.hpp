@@ -562,6 +562,13 @@ struct RobotAssembly {
     static constexpr bool CUSTOM_STEP = false, RET_F32 = false;
     static constexpr int STEP_BLOCK = 256, STEP_WAVES = 5;
     static constexpr int ROLLOUT_WAVES = 3;       // same, for the fused rollout kernels
+    // batches that leave one wave per SIMD: producer / integrator / recorder wave per 64 lanes (nig_split.hpp).  No step
+    // noise, so the producer only loads and clips actions; the recorder takes the fp64 reward, the tally and the 24-row
+    // stores off the wave that runs the seven fp64 sincos.  Not in rounds: larger batches fill the SIMDs with lanes.
+#ifndef NIG_RA_SPLIT_ROUNDS
+#define NIG_RA_SPLIT_ROUNDS false
+#endif
+    static constexpr bool SPLIT_ROLLOUT = true, SPLIT_ROUNDS = NIG_RA_SPLIT_ROUNDS;
     using reward_t = double;
     __device__ static constexpr float act_low(int) { return -1.0f; }
     __device__ static constexpr float act_high(int) { return 1.0f; }

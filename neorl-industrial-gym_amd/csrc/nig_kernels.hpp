@@ -1657,7 +1657,7 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
 {
     const unsigned n_full = q.s.B / BLOCK;
     RolloutArgs r = q;
-    if constexpr (PAIRED && split_rollout<Env>::value) {
+    if constexpr ((PAIRED || Env::KS == 0) && split_rollout<Env>::value) {
         // Up to one 256-lane block per CU the batch leaves a single wave on every SIMD: producer / integrator /
         // recorder wave per 64 lanes instead (nig_split.hpp; one block per CU is resident).  Larger batches run that
         // form in ROUNDS of one block per CU, which beats the one-wave form (lanes filling the SIMDs) by 4-12 % when
@@ -1666,7 +1666,8 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
         const unsigned per_round = q.s.split_blocks;       // nig_tune(NIG_TUNE_SPLIT_BLOCKS), default: the device's compute units
         const unsigned last_round = per_round ? n_full % per_round : 0u;
-        const bool even_rounds = per_round != 0 && (n_full <= per_round || last_round == 0 || 4u * last_round >= 3u * per_round);
+        const bool even_rounds = per_round != 0 && (n_full <= per_round ||
+                                                    (split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
         if (plain && n_full > 0 && even_rounds) {
             r.block0 = 0;
             launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
@@ -1735,7 +1736,7 @@ static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, 
 template <class Env>
 static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
 {
-    if constexpr (split_rollout<Env>::value) {
+    if constexpr (split_rollout<Env>::value && Env::SHARED_STEP_BLOCK) {     // (the closed-loop form exists for ChemicalReactor's shape)
         // Producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp) for the batch's whole 256-lane blocks --
         // up to one block per CU, and larger batches in rounds under the rule of the open-loop rollout (the last round at
         // least 3/4 full) -- and the one-wave kernel for a ragged last block.  (Round 2 sent a batch with a ragged tail,

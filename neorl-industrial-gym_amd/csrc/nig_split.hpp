@@ -33,10 +33,16 @@ namespace nig {
 
 template <class E, class = void> struct split_rollout : std::false_type {};
 template <class E> struct split_rollout<E, std::void_t<decltype(E::SPLIT_ROLLOUT)>> : std::bool_constant<E::SPLIT_ROLLOUT> {};
+// batches of more blocks than are resident at once: run the three-wave form in rounds (ChemicalReactor: measured faster,
+// profiles/r02/rounds_probe.txt), or leave them to the form that fills the SIMDs with lanes (SPLIT_ROUNDS = false)
+template <class E, class = void> struct split_rounds : std::true_type {};
+template <class E> struct split_rounds<E, std::void_t<decltype(E::SPLIT_ROUNDS)>> : std::bool_constant<E::SPLIT_ROUNDS> {};
 
 template <class Env, int NP>
 struct SplitLds {
-    static constexpr int K = 6;                  // ring slots
+    // ring slots: as many as the CU's LDS holds for NP triples (ChemicalReactor, S = 12: six; RobotAssembly, S = 24, whose
+    // producer and recorder are light next to the integrator and never need to run far ahead / behind: three)
+    static constexpr int K = Env::S > 16 ? 3 : 6;
     static constexpr int HI_ROWS = Env::KS + Env::A;
     static constexpr int HI_SLOT = HI_ROWS * 64;             // floats
     static constexpr int IH_SLOT = (Env::S + 1) * 64;        // floats: [64][S] state rows, then [64] violation words
@@ -91,13 +97,17 @@ __device__ __forceinline__ void split_post(lds_u32_t *cnt, uint32_t v, unsigned 
 
 // NP wave triples per block: wave w < NP integrates lanes base + 64 w .. + 63, wave NP + w is their producer and
 // wave 2 NP + w their recorder (a block's waves go to the CU's four SIMDs round-robin: with NP = 4 the three
-// share one).  Whole 64*NP-lane blocks only, auto-reset handles without frozen lanes only, launch starting on an
-// odd counter (PAIRED form): the host keeps every other case on rollout_kernel.
+// share one).  Whole 64*NP-lane blocks only, auto-reset handles without frozen lanes only, and for an env with step
+// noise a launch starting on an odd counter (PAIRED form): the host keeps every other case on rollout_kernel.
 template <class Env, int OUT, int NP>
 __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS;
-    static_assert(Env::SHARED_STEP_BLOCK && Env::COOP_RESET && !Env::CUSTOM_STEP && KS == 2 && S % 4 == 0, "written for ChemicalReactor's shape");
+    // step noise, if any, in ChemicalReactor's shape (two normals per step from one Philox block per two steps); an env
+    // without step noise (RobotAssembly, KS = 0) leaves the producer the action load + clip only
+    static_assert(Env::COOP_RESET && !Env::CUSTOM_STEP && S % 4 == 0 && (KS == 0 || (Env::SHARED_STEP_BLOCK && KS == 2)),
+                  "three-wave form: cooperative reset, S a multiple of 4, no step noise or ChemicalReactor's");
+    constexpr int KN = KS > 0 ? KS : 1;
     using Lds = SplitLds<Env, NP>;
     constexpr int K = Lds::K;
     constexpr int THREADS = 192 * NP;
@@ -145,8 +155,9 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             const uint32_t c_next = split_peek(sync + 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             read_inputs(nslot, in_next);
-            double nz[KS];
+            double nz[KN];
             float a[A];
+            nz[0] = 0.0;
 #pragma unroll
             for (int k = 0; k < KS; ++k) nz[k] = (double)in[k];
 #pragma unroll
@@ -210,16 +221,18 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         auto produce = [&](auto r_tag, const int j) __attribute__((always_inline)) {
             constexpr int r = decltype(r_tag)::value;
             float (&ab)[A] = buf[r];
-            ProbitFetch pf[KS];
-            if constexpr ((r & 1) == 0) {         // first step of a pair: the pair's Philox block
-                const u32x4 x = Env::step_block(make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit));
-                Env::step_noise_fetch(x.x, x.y, s_probit, pf);
-                kept0 = x.z; kept1 = x.w;
-            } else {
-                Env::step_noise_fetch(kept0, kept1, s_probit, pf);
+            typename Env::fast_noise_t nz[KN];
+            if constexpr (KS > 0) {
+                ProbitFetch pf[KN];
+                if constexpr ((r & 1) == 0) {     // first step of a pair: the pair's Philox block
+                    const u32x4 x = Env::step_block(make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit));
+                    Env::step_noise_fetch(x.x, x.y, s_probit, pf);
+                    kept0 = x.z; kept1 = x.w;
+                } else {
+                    Env::step_noise_fetch(kept0, kept1, s_probit, pf);
+                }
+                Env::step_noise_eval(pf, nz);
             }
-            typename Env::fast_noise_t nz[KS];
-            Env::step_noise_eval(pf, nz);
             float a[A];
 #pragma unroll
             for (int k = 0; k < A; ++k) a[k] = ab[k];

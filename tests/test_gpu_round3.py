@@ -238,18 +238,20 @@ def rel_err_np(a, b, floor=1e-6):
     return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
 
 
-def test_three_wave_form_rows_against_oracle_trajectories(ni, oracle):
+@pytest.mark.parametrize("name,key,kernel", [("ChemicalReactor-v0", "cr", "split_rollout_kernel<ChemicalReactor,3,4>"),
+                                             ("RobotAssembly-v0", "ra", "split_rollout_kernel<RobotAssembly,3,4>")])
+def test_three_wave_form_rows_against_oracle_trajectories(ni, oracle, name, key, kernel):
     """The three-wave rollout (csrc/nig_split.hpp) checked DIRECTLY against the oracle, not through the one-wave form:
     the knob is forced, the host rule is asserted to select the three-wave kernel, and every row-major trajectory row,
     reward and termination flag of the first and last wave of the batch is compared step by step with the oracle's
     teacher-forced step fed by the generator's own draws (terminal observations included), then the final state."""
     import types
     import bench
-    name, B, T, seed = "ChemicalReactor-v0", 1024, 40, 0x5EED
+    B, T, seed = 1024, 40, 0x5EED
     before = ni.tune()["split_blocks"]
     ni.tune(split_blocks=256)
     try:
-        assert bench.rollout_kernel_name(types.SimpleNamespace(key="cr", B=B, outputs="full", ni=ni)) == "split_rollout_kernel<ChemicalReactor,3,4>"
+        assert bench.rollout_kernel_name(types.SimpleNamespace(key=key, B=B, outputs="full", ni=ni)) == kernel
         env = ni.make_batched(name, B, seed=seed, autoreset=True, tally=True, max_episode_steps=23)    # truncation: resets inside the window
         ring = torch.empty(T, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
         for s in range(T):

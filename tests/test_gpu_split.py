@@ -26,10 +26,10 @@ def _ring(env, R, t0=70):
     return ring
 
 
-def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11, tally=True, env_index0=0, cmask=None):
+def _run(ni, split, B, chunks, outputs, R, max_steps, first_counter=0, seed=11, tally=True, env_index0=0, cmask=None, name=NAME):
     """Roll `chunks` (list of step counts) through one handle; returns every observable as CPU tensors."""
     ni.tune(split_blocks=256 if split else 0)
-    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=tally, max_episode_steps=max_steps, env_index0=env_index0)
+    env = ni.make_batched(name, B, seed=seed, autoreset=True, tally=tally, max_episode_steps=max_steps, env_index0=env_index0)
     if cmask is not None:
         env.set_constraint_mask(cmask)
     ring = _ring(env, R)
@@ -110,6 +110,40 @@ def test_split_form_handle_variants(ni, kw):
     a, _ = _run(ni, True, **args)
     b, _ = _run(ni, False, **args)
     _same(a, b)
+
+
+RA = "RobotAssembly-v0"
+
+
+@pytest.mark.parametrize("outputs", ["none", "last", "rows", "soa", "aos"])
+@pytest.mark.parametrize("B", [1024, 2500])
+def test_split_form_robot_assembly_equals_one_wave_form(ni, outputs, B):
+    """RobotAssembly (S = 24, A = 7, no step noise: the producer only loads and clips actions; three ring slots) in
+    the three-wave form against rollout_kernel: 41 steps over a 7-slot ring, 20-step episodes plus the env's own
+    terminations (workspace / velocity limits), in-kernel cooperative resets in most steps."""
+    kw = dict(B=B, chunks=[41], outputs=outputs, R=7, max_steps=20, name=RA)
+    a, ca = _run(ni, True, **kw)
+    b, cb = _run(ni, False, **kw)
+    assert ca == cb == 41
+    _same(a, b)
+    assert float(a[-1][0].sum()) > 0
+
+
+@pytest.mark.parametrize("first_counter", [0, 1])
+def test_split_form_robot_assembly_chunks_lengths_and_variants(ni, first_counter):
+    """Consecutive launches of every short length (the producer's look-ahead tail cases) on one handle, from even and
+    odd launch counters (no pairing for an env without step noise: both start in the three-wave form), then handles
+    without the tally, at a shard offset and with constraints masked."""
+    kw = dict(B=768, chunks=[5, 1, 8, 2, 3, 4, 6, 7, 11], outputs="rows", R=5, max_steps=9, first_counter=first_counter, name=RA)
+    a, ca = _run(ni, True, **kw)
+    b, cb = _run(ni, False, **kw)
+    assert ca == cb == first_counter + 47
+    _same(a, b)
+    for v in (dict(tally=False), dict(env_index0=3 * 65536 + 512, seed=0xABCDEF), dict(cmask=0b101), dict(cmask=0)):
+        args = dict(B=512, chunks=[23, 10], outputs="aos", R=6, max_steps=12, name=RA, **v)
+        a, _ = _run(ni, True, **args)
+        b, _ = _run(ni, False, **args)
+        _same(a, b)
 
 
 def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
