@@ -157,6 +157,26 @@ __device__ __forceinline__ float det_sinf(float x)
     return v;
 }
 
+// Thresholds for comparing a float32 value with a double constant in float32: for every float x (NaN and infinities
+// included), (double)x <= c  <=>  x <= f32_not_above(c) and (double)x >= c  <=>  x >= f32_not_below(c), because the
+// conversion is exact and no float lies strictly between the threshold and c.  (c finite, nonzero or exactly 0.)
+constexpr float f32_not_above(double c)
+{
+    const float f = (float)c;
+    if ((double)f <= c) return f;
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return __builtin_bit_cast(float, f > 0.0f ? b - 1u : b + 1u);        // one float down
+}
+constexpr float f32_not_below(double c)
+{
+    const float f = (float)c;
+    if ((double)f >= c) return f;
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return __builtin_bit_cast(float, f > 0.0f ? b + 1u : b - 1u);        // one float up
+}
+static_assert(f32_not_above(0.8) == 0.79999995f && f32_not_above(0.5) == 0.5f && f32_not_below(-0.1) == -0.099999994f &&
+              f32_not_below(-0.6) == -0.59999996f && f32_not_above(0.9) == 0.9f && (double)f32_not_above(0.6) <= 0.6, "float thresholds");
+
 // double sin/cos for joint angles (|x| small multiples of pi): Cody-Waite with a 33-bit
 // pi/2 head (k*head exact), fdlibm kernel polynomials.  Stands in for np.sin/np.cos on
 // float64 scalars (robot_assembly.py:103-107).
@@ -166,27 +186,32 @@ __device__ __forceinline__ void det_sincos(double x, double &s, double &c)
     double r = __builtin_fma(-fk, 1.57079632673412561417e+00, x);
     r = __builtin_fma(-fk, 6.07710050650619224932e-11, r);
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    // the two Horner chains written step by step side by side: independent instructions alternate (a lone wave waits
+    // out the latency of every dependent fp64 operation)
+    double ps = 1.58969099521155010221e-10, pc = -1.13596475577881948265e-11;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08); pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04); pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01); pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
     const double sn = __builtin_fma(r * z, ps, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
     const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    const int q = (int)((long long)fk & 3);
-    const bool swap = (q & 1) != 0;
-    double ss = swap ? cs : sn;
-    double cc = swap ? sn : cs;
-    ss = (q & 2) ? -ss : ss;
-    cc = ((q + 1) & 2) ? -cc : cc;
-    s = ss; c = cc;
+    // quadrant q = fk mod 4 from the low mantissa word of fk + 1.5 * 2^52 (two's complement of fk there for
+    // |fk| < 2^51; the oracle states it the same way): ONE add where a double -> integer conversion is four
+    // instructions.  Quadrant 1, 3: sin and cos trade places (bit select under an all-ones / all-zeros mask);
+    // sin is negated in quadrants 2, 3 and cos in 1, 2: bit 1 of q / of q + 1 moved onto the sign bit, one shift and one
+    // three-input bit operation each.  RobotAssembly runs seven of these per step and is bound by instruction issue.
+    const uint32_t q = (uint32_t)(unsigned long long)__double_as_longlong(fk + 6755399441055744.0);
+    const uint32_t swap = (uint32_t)__builtin_amdgcn_sbfe((int32_t)q, 0, 1);      // all ones in quadrants 1, 3
+    const unsigned long long bs = (unsigned long long)__double_as_longlong(sn), bc = (unsigned long long)__double_as_longlong(cs);
+    const uint32_t s_lo = (uint32_t)bs, s_hi = (uint32_t)(bs >> 32), c_lo = (uint32_t)bc, c_hi = (uint32_t)(bc >> 32);
+    // bit select (a & b) | (~a & c): truth table 0xca
+    const uint32_t ss_lo = __builtin_amdgcn_bitop3_b32(swap, c_lo, s_lo, 0xca), ss_hi = __builtin_amdgcn_bitop3_b32(swap, c_hi, s_hi, 0xca);
+    const uint32_t cc_lo = __builtin_amdgcn_bitop3_b32(swap, s_lo, c_lo, 0xca), cc_hi = __builtin_amdgcn_bitop3_b32(swap, s_hi, c_hi, 0xca);
+    const uint32_t ss_h = __builtin_amdgcn_bitop3_b32(q << 30, 0x80000000u, ss_hi, 0x6a);          // (a & b) ^ c
+    const uint32_t cc_h = __builtin_amdgcn_bitop3_b32((q + 1u) << 30, 0x80000000u, cc_hi, 0x6a);
+    s = __longlong_as_double((long long)(((unsigned long long)ss_h << 32) | ss_lo));
+    c = __longlong_as_double((long long)(((unsigned long long)cc_h << 32) | cc_lo));
 }
 
 // ---------------------------------------------------------------------------------

@@ -664,8 +664,11 @@ struct RobotAssembly {
         bool f_ok = true, c_ok = true, v_ok = true;
 #pragma unroll
         for (int i = 0; i < 3; ++i) f_ok = f_ok & (fabsf(s[18 + i]) < 50.0f);           // :15-16
-        c_ok = ((double)s[0] >= -0.5) & ((double)s[0] <= 0.5) & ((double)s[1] >= -0.5) &
-               ((double)s[1] <= 0.5) & ((double)s[2] >= 0.0) & ((double)s[2] <= 0.8);     // :24-26 fp64 bounds
+        // :24-26 compares a float32 state value with Python floats, i.e. in fp64: for a float x, (double)x <= c holds
+        // exactly when x <= the largest float not above c (and >= likewise), so the six compares run in float32 --
+        // an fp64 compare costs a conversion and two wait states before its result can be used
+        c_ok = (s[0] >= f32_not_below(-0.5)) & (s[0] <= f32_not_above(0.5)) & (s[1] >= f32_not_below(-0.5)) &
+               (s[1] <= f32_not_above(0.5)) & (s[2] >= f32_not_below(0.0)) & (s[2] <= f32_not_above(0.8));
 #pragma unroll
         for (int i = 0; i < 7; ++i) v_ok = v_ok & (fabsf(s[7 + i]) < 2.0f);             // :30-32
         return (f_ok ? 0u : 1u) | (c_ok ? 0u : 2u) | (v_ok ? 0u : 4u);
@@ -675,10 +678,33 @@ struct RobotAssembly {
     __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const double (&)[1],
                                     float dt32, double dt, float (&o)[S])
     {
+        float qf[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) qf[i] = s[7 + i] + a[i] * dt32;              // :148 float32
         double q[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) q[i] = (double)(s[7 + i] + a[i] * dt32);     // :148 float32
+        for (int i = 0; i < 7; ++i) q[i] = (double)qf[i];
+        // fp64 clip to [-pi, pi] :149-153.  Fourteen compares and 28 selects that change nothing unless a joint has
+        // left the interval (a random walk of +-0.1 rad steps from +-pi/2 inside an episode of a few dozen steps:
+        // almost never): the wave looks at max |q| first -- 0x40490FDA is the largest float not above the double pi,
+        // so a float within it is inside the fp64 interval, and a NaN (which the clip leaves alone, as np.clip does)
+        // does not raise the maximum -- and skips the clip when no lane needs it.  Same values either way.
+        float m;
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(qf[0]), "v"(qf[1]), "v"(qf[2]));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(qf[3]), "v"(qf[4]));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(qf[5]), "v"(qf[6]));
+        if (__builtin_amdgcn_ballot_w64(!(m <= __uint_as_float(0x40490FDAu))) != 0ull) clip_joints(q);
         dynamics_from_joints(s, q, dt, o);
+    }
+    __device__ static void clip_joints(double (&q)[7])
+    {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {                                    // fp64 clip :149-153
+            double d = q[i];
+            d = (d < -PI) ? -PI : d;
+            d = (d > PI) ? PI : d;
+            q[i] = d;
+        }
     }
     // float64 actions (robot_assembly.py:266-290 hands them over; pinned by ra_g5.npz, ra_g6.npz): :148 is float64
     static constexpr bool HAS_ACT64 = true;
@@ -693,6 +719,7 @@ struct RobotAssembly {
         double q[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) q[i] = (double)s[7 + i] + a[i] * dt;
+        clip_joints(q);
         dynamics_from_joints(s, q, dt, o);
     }
     __device__ static double reward(const float (&n)[S], const double (&a)[A])
@@ -702,15 +729,8 @@ struct RobotAssembly {
         for (int i = 0; i < 7; ++i) ap = ap + a[i] * a[i];               // :211 float64, sequential
         return reward_with_penalty(n, -0.1 * ap);
     }
-    __device__ static void dynamics_from_joints(const float (&s)[S], double (&q)[7], double dt, float (&o)[S])
+    __device__ static void dynamics_from_joints(const float (&s)[S], double (&q)[7], double dt, float (&o)[S])   // q: clipped
     {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {                                    // fp64 clip :149-153
-            double d = q[i];
-            d = (d < -PI) ? -PI : d;
-            d = (d > PI) ? PI : d;
-            q[i] = d;
-        }
         double x, y, z;
         fk(q, x, y, z);                                                  // :156
         const double vx = (x - (double)s[0]) / dt, vy = (y - (double)s[1]) / dt, vz = (z - (double)s[2]) / dt; // :159-160
@@ -764,8 +784,8 @@ struct RobotAssembly {
         bool d = n[23] > 0.95f;                                          // :231
 #pragma unroll
         for (int i = 0; i < 3; ++i) d = d | (fabsf(n[18 + i]) > 80.0f);  // :235
-        const bool inside = ((double)n[0] >= -0.6) & ((double)n[0] <= 0.6) & ((double)n[1] >= -0.6) &
-                            ((double)n[1] <= 0.6) & ((double)n[2] >= -0.1) & ((double)n[2] <= 0.9);     // :239-242
+        const bool inside = (n[0] >= f32_not_below(-0.6)) & (n[0] <= f32_not_above(0.6)) & (n[1] >= f32_not_below(-0.6)) &
+                            (n[1] <= f32_not_above(0.6)) & (n[2] >= f32_not_below(-0.1)) & (n[2] <= f32_not_above(0.9));   // :239-242 (fp64 bounds, see violated)
         return d || !inside;
     }
 };

@@ -117,8 +117,14 @@ static void det_sincos(double x, double *s, double *c)
     pc = fma(pc, z, -1.38888888888741095749e-03);
     pc = fma(pc, z, 4.16666666666666019037e-02);
     double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
-    long long q = (long long)fk;
-    switch ((int)(q & 3)) {
+    /* quadrant = fk mod 4, read from the low mantissa bits of fk + 1.5 * 2^52 (the two's complement of fk for
+     * |fk| < 2^51, i.e. everywhere the two-constant reduction above means anything; defined, unlike a cast, for every
+     * other double as well): the statement the device code uses, so that the two agree on ALL inputs */
+    double km = fk + 6755399441055744.0;
+    uint64_t kb;
+    memcpy(&kb, &km, sizeof kb);
+    uint32_t q = (uint32_t)kb;
+    switch ((int)(q & 3u)) {
     case 0: *s = sn;  *c = cs;  break;
     case 1: *s = cs;  *c = -sn; break;
     case 2: *s = -sn; *c = -cs; break;

@@ -10,7 +10,10 @@ for r in 1 2; do
   done; done
   unset NIG_SPLIT_BLOCKS
   run one-wave 262144 full
-  NIG_LIB_PATH=$PWD/neorl-industrial-gym_amd/libnig_rarounds.so run rounds 262144 full
-  NIG_LIB_PATH=$PWD/neorl-industrial-gym_amd/libnig_rarounds.so run rounds 131072 full
+  run one-wave 262144 min
   NIG_SPLIT_BLOCKS=0 run one-wave 131072 full
+  if [ -f $PWD/neorl-industrial-gym_amd/libnig_rarounds.so ]; then
+    NIG_LIB_PATH=$PWD/neorl-industrial-gym_amd/libnig_rarounds.so run rounds 262144 full
+    NIG_LIB_PATH=$PWD/neorl-industrial-gym_amd/libnig_rarounds.so run rounds 131072 full
+  fi
 done
