@@ -28,6 +28,25 @@ __device__ __forceinline__ float fdiv_c(float x, const float c)
     return __builtin_amdgcn_div_fixupf(q, c, x);
 }
 
+// a / b in fp64 for a divisor b that is a constant or shared by the wave, y = RN(1 / b) (an IEEE division folded at
+// compile time or done once per launch), correctly rounded like NumPy's division in 6 instructions instead of the 13
+// of the generic sequence (two v_div_scale, a quarter-rate v_rcp_f64, seven fma, v_div_fmas, v_div_fixup):
+//   q0 = RN(a y);  q1 = RN(q0 + RN(a - b q0) y);  q2 = RN(q1 + (a - b q1) y);  v_div_fixup for the special cases.
+// q0 is within 1.5 ulp of a / b, so q1 differs from a / b by less than 2^-100 relative before its rounding: a faithful
+// quotient.  With a faithful q1 the residual a - b q1 is exact in one fma, and Markstein's theorem (Markstein 1990;
+// Muller et al., Handbook of Floating-Point Arithmetic, "division with a correctly rounded reciprocal") gives
+// q2 = RN(a / b) for every a when y is the correctly rounded reciprocal.  Needs a y, q b and the residual inside the
+// normal range: callers pass quantities of order 1e-20 .. 1e10 and divisors between 2^-100 and 2^100 (a caller with a
+// user-chosen divisor checks that and divides the long way otherwise).  tests/ddiv_check.c compares the sequence with
+// IEEE division on 10^8 operands, including quotients placed next to rounding boundaries.
+__device__ __forceinline__ double ddiv_y(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double q1 = __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+    const double q2 = __builtin_fma(__builtin_fma(-q1, b, a), y, q1);
+    return __builtin_amdgcn_div_fixup(q2, b, a);
+}
+
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
 

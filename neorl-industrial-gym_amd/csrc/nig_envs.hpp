@@ -505,7 +505,7 @@ struct PowerGrid {
         double cg[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) cg[i] = gen_cost(i) * (double)g[i];
-        return (-sum8(cg)) / 1000.0;
+        return ddiv_y(-sum8(cg), 1000.0, 1.0 / 1000.0);
     }
     __device__ static float reward_act(const float (&a)[A])                              // :173
     {
@@ -733,7 +733,15 @@ struct RobotAssembly {
     {
         double x, y, z;
         fk(q, x, y, z);                                                  // :156
-        const double vx = (x - (double)s[0]) / dt, vy = (y - (double)s[1]) / dt, vz = (z - (double)s[2]) / dt; // :159-160
+        // :159-160 three divisions by dt, the same for every lane: by its reciprocal with the correctly rounded
+        // correction of ddiv_y (nig_detmath.hpp) while dt is an ordinary step size, the IEEE sequence otherwise
+        double vx, vy, vz;
+        if (dt >= 0x1p-100 && dt <= 0x1p100) {
+            const double rdt = 1.0 / dt;
+            vx = ddiv_y(x - (double)s[0], dt, rdt); vy = ddiv_y(y - (double)s[1], dt, rdt); vz = ddiv_y(z - (double)s[2], dt, rdt);
+        } else {
+            vx = (x - (double)s[0]) / dt; vy = (y - (double)s[1]) / dt; vz = (z - (double)s[2]) / dt;
+        }
         const double dx = x - 0.3, dy = y - 0.0, dz = z - 0.4;           // target :90
         const double dist = sqrt(dx * dx + dy * dy + dz * dz);           // :163
         double fz = 0.0;
@@ -742,9 +750,9 @@ struct RobotAssembly {
             fz = (nf == 0.0) ? 0.0 : (0.0 - nf);
         }
         const double ae = sqrt(dx * dx + dy * dy);                       // :172
-        const double align = pymax(0.0, 1.0 - ae / 0.005);               // :173
+        const double align = pymax(0.0, 1.0 - ddiv_y(ae, 0.005, 1.0 / 0.005));   // :173
         const double ins = pymax(0.0, 0.4 - z);                          // :175
-        const double depth = pymin(1.0, ins / 0.05);                     // :176
+        const double depth = pymin(1.0, ddiv_y(ins, 0.05, 1.0 / 0.05));  // :176
         o[0] = (float)x; o[1] = (float)y; o[2] = (float)z;
         o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f;              // :182
 #pragma unroll
@@ -870,6 +878,12 @@ struct SpecPlant {
         n[1] = (double)(P.nsd[1] * z[1]);
     }
 
+    // The plant model's clip(v, lo, hi) (spec_plants.py): the larger of v and lo, then the smaller of that and hi; a NaN
+    // becomes lo, a zero at a zero limit takes the limit's sign.  That is what ONE v_med3_f32 computes (a NaN input
+    // makes it return the minimum of the others), where two compare + select pairs are four instructions: the four
+    // plants clip 12 to 25 values per step.
+    __device__ static float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+
     // box constraint c: every row of [cfirst, cfirst + ccount) inside [clo, chi]; bit set = violated
     __device__ static uint32_t violated(const float (&s)[S], const float (&)[A])
     {
@@ -894,7 +908,7 @@ struct SpecPlant {
         float e = 0.0f;
 #pragma unroll
         for (int j = 0; j < A; ++j) {              // velocity-form actuators, clipped to [0, 1]
-            pn[j] = pymax(0.0f, pymin(1.0f, s[NP + j] + (P.rate[j] * a[j]) * dt32));
+            pn[j] = clamp(s[NP + j] + (P.rate[j] * a[j]) * dt32, 0.0f, 1.0f);
             e = e + P.ecost[j] * pn[j];
         }
 #pragma unroll
@@ -905,7 +919,7 @@ struct SpecPlant {
                 if (P.G[i][j] != 0.0f) dy = dy + P.G[i][j] * pn[j];
             if (P.cpl[i] != 0.0f) dy = dy + P.cpl[i] * (s[P.cidx[i]] - s[i]);
             if (i < KS) dy = dy + (float)nz[i];
-            o[i] = pymax(P.ymin[i], pymin(P.ymax[i], s[i] + dy * dt32));
+            o[i] = clamp(s[i] + dy * dt32, P.ymin[i], P.ymax[i]);
         }
 #pragma unroll
         for (int j = 0; j < A; ++j) o[NP + j] = pn[j];

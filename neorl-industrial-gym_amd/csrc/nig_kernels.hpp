@@ -84,8 +84,16 @@ __device__ __forceinline__ void clip_action(AT (&a)[Env::A])
 #pragma unroll
     for (int k = 0; k < Env::A; ++k) {            // base.py:167 np.clip(action, -1, 1) == min(max(x,lo),hi)
         AT x = a[k];
-        x = (x < (AT)-1) ? (AT)-1 : x;
-        x = (x > (AT)1) ? (AT)1 : x;
+        if constexpr (std::is_same<AT, float>::value) {
+            // NumPy's maximum / minimum hand a NaN on, and so do gfx950's v_maximum3_f32 / v_minimum3_f32 (IEEE 754-2019
+            // maximum / minimum): two instructions where compare + select pairs are four.  (Neither limit is a zero,
+            // so the sign of a zero result never comes from a limit; an action inside the limits is returned as it is.)
+            x = __builtin_elementwise_maximum(x, -1.0f);
+            x = __builtin_elementwise_minimum(x, 1.0f);
+        } else {
+            x = (x < (AT)-1) ? (AT)-1 : x;
+            x = (x > (AT)1) ? (AT)1 : x;
+        }
         a[k] = x;
     }
 }

@@ -17,6 +17,9 @@ increment); three accounting rows (instantaneous effort, its integral, elapsed t
     e'    = sum_j ecost_j p_j';   E' = E + e' dt;   t' = t + dt
     reward = -sum_i w_i |y_i' - sp_i| - we e' - wu sum_j |a_j|  (+ bonus while constraint 0 holds)
 
+clip(v, lo, hi) = min(max(v, lo), hi) on float32 with a NaN mapped to lo (IEEE maxNum / minNum: one v_med3_f32 on
+the device, two compares in the CPU statement).
+
 State layout: [y_0..y_NP-1, p_0..p_A-1, e, E, t], all float32, evaluated in exactly this order
 with one rounding per operation (csrc/nig_envs.hpp SpecPlant<K>; the tests' CPU restatement mirrors it).
 Each safety constraint is a box over a run of state rows.

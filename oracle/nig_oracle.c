@@ -241,12 +241,19 @@ static void sp_reset(const spec_plant_t *P, const double *n, float *s)
     for (int j = 0; j < P->na; j++) s[P->np + j] = 0.5f;
     s[P->np + P->na] = 0.0f; s[P->np + P->na + 1] = 0.0f; s[P->np + P->na + 2] = 0.0f;
 }
+/* the plant model's clip (spec_plants.py): the larger of v and lo, then the smaller of that and hi; NaN -> lo; a zero
+ * at a zero limit takes the limit's sign (written with compares: C's fmaxf leaves the sign of max(-0, +0) open) */
+static float sp_clipf(float v, float lo, float hi)
+{
+    float t = (v > lo) ? v : lo;
+    return (t < hi) ? t : hi;
+}
 static void sp_dynamics(const spec_plant_t *P, const float *s, const float *a, const double *nz, float dt, float *o)
 {
     const int np = P->np, na = P->na;
     float pn[10], e = 0.0f;
     for (int j = 0; j < na; j++) {
-        pn[j] = pymaxf(0.0f, pyminf(1.0f, s[np + j] + (P->rate[j] * a[j]) * dt));
+        pn[j] = sp_clipf(s[np + j] + (P->rate[j] * a[j]) * dt, 0.0f, 1.0f);
         e = e + P->ecost[j] * pn[j];
     }
     for (int i = 0; i < np; i++) {
@@ -254,7 +261,7 @@ static void sp_dynamics(const spec_plant_t *P, const float *s, const float *a, c
         for (int j = 0; j < na; j++) if (P->G[i][j] != 0.0f) dy = dy + P->G[i][j] * pn[j];
         if (P->cpl[i] != 0.0f) dy = dy + P->cpl[i] * (s[P->cidx[i]] - s[i]);
         if (i < 2) dy = dy + (float)nz[i];
-        o[i] = pymaxf(P->ymin[i], pyminf(P->ymax[i], s[i] + dy * dt));
+        o[i] = sp_clipf(s[i] + dy * dt, P->ymin[i], P->ymax[i]);
     }
     for (int j = 0; j < na; j++) o[np + j] = pn[j];
     o[np + na] = e;

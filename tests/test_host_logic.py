@@ -210,6 +210,23 @@ def test_constant_division_is_correctly_rounded(tmp_path):
     assert out.stdout.count("mismatches=0") == len(consts), out.stdout
 
 
+def test_fp64_division_by_a_shared_divisor_is_correctly_rounded(tmp_path):
+    """ddiv_y (csrc/nig_detmath.hpp: product with the reciprocal + two fused corrections, Markstein) against IEEE fp64
+    division on 3.6e7 operands per divisor -- random binades, RobotAssembly's x - s0 differences, numerators placed at
+    rounding boundaries of the quotient -- for every constant divisor the device code uses and a set of step sizes."""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "neorl-industrial-gym_amd", "csrc", "nig_envs.hpp")).read()
+    consts = sorted({m.group(1) for m in re.finditer(r"ddiv_y\([^;]*?,\s*([0-9.eE+-]+),\s*1\.0\s*/", src)})
+    assert set(consts) >= {"0.005", "0.05", "1000.0"}, consts
+    exe = tmp_path / "ddiv_check"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe), os.path.join(ROOT, "tests", "ddiv_check.c"), "-lm"], check=True)
+    divisors = consts + ["0.1", "0.01", "0.02", "0.05", "0.001", "0.25", "1.0", "0.3333333333333333", "7.0", "1e-30", "1e30"]
+    out = subprocess.run([str(exe), "1000000"] + divisors, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert out.stdout.count("mismatches=0") == len(divisors), out.stdout[-2000:]
+
+
 def test_probit_table_with_folded_scale_is_bit_identical(tmp_path):
     """The normal transform's table stores {c0, c1 2^-18, c2 2^-36, c3 2^-54} and the position in a piece is taken as
     an integer (one multiply less per normal): over all 768 x 2^18 inputs the result has the same bits as the unscaled

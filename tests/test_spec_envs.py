@@ -116,6 +116,39 @@ def test_step_kernel_bit_identical_to_cpu_statement(ni, oracle, key, B, T, max_s
 
 @gpu
 @pytest.mark.parametrize("key", list(SPEC))
+def test_clip_special_values_match_the_cpu_statement(ni, oracle, key):
+    """The plant model's clip is one v_med3_f32 on the device and two compares in the CPU statement: signed zeros at
+    zero limits, values far outside the limits, infinities and NaN in process variables and actuator positions (and
+    -0.0 / huge actions) come out bit-identical, in next state, termination and violation count."""
+    import torch
+    name, S, A = SPEC[key]
+    B, seed = 256, 0x5EED
+    env = ni.make_batched(name, B, seed=seed, autoreset=False, tally=False)
+    env.reset()
+    st = env.get_state().cpu().numpy().copy()
+    rng = np.random.default_rng(7)
+    special = np.array([-0.0, 0.0, np.nan, np.inf, -np.inf, 1e30, -1e30, 1.0, -1.0, 1e-40, -1e-40], dtype=np.float32)
+    for i in range(B):
+        for c in rng.choice(S - 3, size=1 + i % 4, replace=False):       # process variables and actuator positions
+            st[i, c] = special[rng.integers(len(special))]
+    env.set_state(st)
+    act = rng.uniform(-1.0, 1.0, size=(B, A)).astype(np.float32)
+    act[::5, 0] = -0.0
+    act[1::7, A - 1] = 1e30
+    a_dev = torch.as_tensor(act.T.copy(), device=env.device)
+    obs, rew, te, tr, info = env.step(a_dev, layout="soa")
+    got = env.get_state().cpu().numpy()
+    noise = np.stack([oracle.gen_step_noise(name, seed, i, 1) for i in range(B)])
+    act_clipped = np.clip(act, -1.0, 1.0)                                  # base.py:167 (finite actions here)
+    r = oracle.step(name, st, act_clipped, noise, np.zeros(B, dtype=np.int32), flavor=oracle.MATH_POLY)
+    assert np.array_equal(got.view(np.uint32), r["state_next"].view(np.uint32))
+    assert np.array_equal(te.cpu().numpy().astype(bool), r["terminated"] != 0)
+    assert np.array_equal(info.violation_count.cpu().numpy(), r["viol"])
+    env.close()
+
+
+@gpu
+@pytest.mark.parametrize("key", list(SPEC))
 def test_fused_rollout_all_output_shapes(ni, oracle, key):
     """Fused rollout == step calls == CPU statement; row-major and [S][ld] trajectories for state dims
     that are not multiples of 4 (18, 15), partial last wave, chunked launches."""
