@@ -410,8 +410,8 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float g = s[9 + i] + a[i];                                   // :124 np.clip(gen + a, 0, 100)
-            g = (g < 0.0f) ? 0.0f : g;
-            g = (g > 100.0f) ? 100.0f : g;
+            g = (g < 0.0f) ? 0.0f : g;                                   // (compare + select: np.maximum keeps a -0.0, v_maximum3_f32 would not)
+            g = __builtin_elementwise_minimum(g, 100.0f);                // np.minimum, NaN handed on: one v_minimum3_f32
             ngen[i] = g;
             load[i] = s[17 + i];
         }

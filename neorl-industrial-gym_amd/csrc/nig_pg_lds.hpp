@@ -111,7 +111,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             for (int i = 0; i < 8; ++i) {
                 float g = s[9 + i] + a[i];                                   // power_grid.py:124 np.clip(gen + a, 0, 100)
                 g = (g < 0.0f) ? 0.0f : g;
-                g = (g > 100.0f) ? 100.0f : g;
+                g = __builtin_elementwise_minimum(g, 100.0f);      // np.minimum incl. NaN: one v_minimum3_f32 (nig_envs.hpp dynamics)
                 ngen[i] = g;
                 load[i] = s[17 + i];
                 v[i] = s[1 + i];
