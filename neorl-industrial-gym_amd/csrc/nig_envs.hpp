@@ -890,14 +890,24 @@ struct SpecPlant {
         constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
         uint32_t v = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            bool ok = true;
-#pragma unroll
-            for (int r = 0; r < S; ++r)
-                if (r >= P.cfirst[c] && r < P.cfirst[c] + P.ccount[c]) ok = ok && (P.clo[c] <= s[r]) && (s[r] <= P.chi[c]);
-            v |= ok ? 0u : (1u << c);
-        }
+        for (int c = 0; c < 3; ++c) v |= box_ok(s, c) ? 0u : (1u << c);
         return v;
+    }
+    // every row of constraint c's run inside [clo, chi].  The run's smallest and largest value decide it: minimum /
+    // maximum trees of gfx950's three-input v_minimum3_f32 / v_maximum3_f32, which hand a NaN on -- so a NaN row fails
+    // both compares, exactly like the row-by-row "lo <= s && s <= hi" chain (two compares and two scalar ands per row;
+    // SupplyChain checks 35 rows per step, two constraints over the same ten).
+    __device__ static bool box_ok(const float (&s)[S], int c)
+    {
+        constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        float mn = s[P.cfirst[c]], mx = mn;
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+            if (r > P.cfirst[c] && r < P.cfirst[c] + P.ccount[c]) {
+                mn = __builtin_elementwise_minimum(mn, s[r]);
+                mx = __builtin_elementwise_maximum(mx, s[r]);
+            }
+        return (P.clo[c] <= mn) & (mx <= P.chi[c]);
     }
 
     __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const double (&nz)[KS],
@@ -940,11 +950,7 @@ struct SpecPlant {
 #pragma unroll
         for (int j = 0; j < A; ++j) ap = ap + fabsf(a[j]);
         r = r - P.wu * ap;
-        bool ok = true;                            // bonus while constraint 0 holds on the new state
-#pragma unroll
-        for (int rr = 0; rr < S; ++rr)
-            if (rr >= P.cfirst[0] && rr < P.cfirst[0] + P.ccount[0]) ok = ok && (P.clo[0] <= n[rr]) && (n[rr] <= P.chi[0]);
-        return ok ? (r + P.bonus) : r;
+        return box_ok(n, 0) ? (r + P.bonus) : r;   // bonus while constraint 0 holds on the new state
     }
 
     __device__ static bool done(const float (&n)[S])
