@@ -317,3 +317,42 @@ def test_pg_lds_rollout_at_the_maximum_batch(ni, wide_knob, oracle):
         assert int(keep.sum()) > 2000
         assert torch.equal(o[keep].view(torch.int32), env.state_soa[:, lo:lo + 4096].t()[keep].contiguous().view(torch.int32))
     env.close()
+
+
+@pytest.mark.parametrize("dt", [None, 0.02, 1e-40, 3e35])
+def test_robot_assembly_clip_division_and_special_states(ni, oracle, dt):
+    """RobotAssembly's rarely taken paths against the oracle, bit for bit (NaN == NaN): joints beyond +-pi (the fp64
+    clip that the kernel skips unless a lane needs it, robot_assembly.py:149-153), -0.0 / NaN joints, infinite and NaN
+    previous positions (the velocity division's special cases, :159-160), actions at and beyond the limits; with the
+    default dt, another ordinary one (division through the reciprocal, csrc/nig_detmath.hpp ddiv_y) and two far outside
+    the range that path is used for (IEEE division), one of them subnormal in float32."""
+    name, B, seed = "RobotAssembly-v0", 512, 0x5EED
+    kw = {} if dt is None else {"dt": dt}
+    env = ni.make_batched(name, B, seed=seed, autoreset=False, tally=False, **kw)
+    env.reset()
+    st = env.get_state().cpu().numpy().copy()
+    rng = np.random.default_rng(11)
+    pi32 = np.float32(np.pi)
+    for i in range(B):
+        k = i % 8
+        if k == 0:   st[i, 7 + rng.integers(7)] = pi32                       # the float above the double pi
+        elif k == 1: st[i, 7 + rng.integers(7)] = -pi32 - np.float32(0.05)
+        elif k == 2: st[i, 7 + rng.integers(7)] = np.float32(3.1415925)     # the largest float inside
+        elif k == 3: st[i, 7 + rng.integers(7)] = np.float32([np.nan, -0.0, 40.0, -1e6][rng.integers(4)])
+        elif k == 4: st[i, rng.integers(3)] = np.float32([np.inf, -np.inf, np.nan, -0.0, 1e30][rng.integers(5)])
+        # k = 5, 6, 7: ordinary rows in the same waves
+    env.set_state(st)
+    act = rng.uniform(-1.0, 1.0, size=(B, 7)).astype(np.float32)
+    act[::3] = np.sign(act[::3])                                             # +-1: pushes joints at the limit across it
+    act[5::16, 2] = 7.5
+    env.step(act)
+    got = env.get_state().cpu().numpy()
+    o = oracle.step(name, st, act, None, np.zeros(B, dtype=np.int32), dt=env.dt, flavor=oracle.MATH_POLY)
+    same = (got.view(np.uint32) == o["state_next"].view(np.uint32)) | (np.isnan(got) & np.isnan(o["state_next"]))
+    assert same.all(), np.argwhere(~same)[:10]
+    fl = env.flags.cpu().numpy()
+    assert np.array_equal((fl & ni._lib.FLAG_TERMINATED) != 0, o["terminated"] != 0)
+    with np.errstate(over="ignore"):
+        want = o["reward"].astype(np.float32)
+    assert np.array_equal(env.reward.cpu().numpy(), want, equal_nan=True)
+    env.close()
