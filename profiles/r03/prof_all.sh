@@ -37,4 +37,4 @@ for k, d in acc.items():
 PY
 cp profiles/traffic.json gpurun_out/r03_traffic_merged.json
 mkdir -p gpurun_out/profiles_r03 && cp -r $R/* gpurun_out/profiles_r03/
-tail -3 gpurun_out/r03_prof_driver.log gpurun_out/r03_pmc_pg.log $R/pg262144_rollout_full_sq.txt $R/mixed1048576_min_sq.txt $R/ra262144_rollout_full_sq.txt $R/mlp_cr65536_sq.txt
+for f in gpurun_out/r03_prof_driver.log gpurun_out/r03_pmc_pg.log $R/pg262144_rollout_full_sq.txt $R/mixed1048576_min_sq.txt $R/ra262144_rollout_full_sq.txt $R/mlp_cr65536_sq.txt; do echo "--- $f"; tail -n 3 $f; done
