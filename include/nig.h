@@ -131,15 +131,15 @@ const char *nig_last_error(void);
 /* Process-wide tuning knobs.  Results never depend on them: every kernel form a knob selects between is
  * bit-identical (tests/test_gpu_split.py).  No counterpart upstream.
  *   NIG_TUNE_SPLIT_BLOCKS   256-lane blocks per ROUND of the three-wave form of nig_rollout / nig_rollout_policy
- *                           (csrc/nig_split.hpp: producer / integrator / recorder wave per 64 ChemicalReactor
- *                           lanes, one block resident per compute unit); default = the compute units of the HANDLE's
+ *                           (csrc/nig_split.hpp: producer / integrator / recorder wave per 64 ChemicalReactor or
+ *                           RobotAssembly lanes, one block resident per compute unit); default = the compute units of the HANDLE's
  *                           device, read at nig_create (256 on an MI355X; nig_tune_get reports it for the device of
  *                           the latest handle), 0 = never use that form.  An explicit value is process-wide and atomic.  nig_rollout
- *                           uses it for batches of at most one round and for larger ones whose last round is at
- *                           least 3/4 full, nig_rollout_policy for at most one round.  The environment variable
+ *                           uses it for batches of at most one round and (ChemicalReactor) for larger ones whose
+ *                           last round is at least 3/4 full, nig_rollout_policy (ChemicalReactor) likewise.  The environment variable
  *                           NIG_SPLIT_BLOCKS sets the initial value.
  *   NIG_TUNE_WIDE_MIN_BLOCKS  smallest batch, in 512-lane blocks, that nig_rollout runs in the WIDE form (csrc/nig_kernels.hpp
- *                           rollout_wide_kernel: PowerGrid / RobotAssembly, 512-thread blocks at four waves per SIMD,
+ *                           rollout_wide_kernel: PowerGrid, 512-thread blocks at four waves per SIMD,
  *                           handles on which no lane can be frozen); default = the compute units of the handle's
  *                           device (one wide block per compute unit); smaller batches run the same LDS-resident
  *                           body in 256-lane blocks; 2^30 or more = never use that body (rollout_kernel only).  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.

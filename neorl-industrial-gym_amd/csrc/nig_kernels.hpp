@@ -673,7 +673,12 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
     uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
     float *obs_row = nullptr;                  // this step's observation block / rows
-    if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S;
+    // (OUT == 3: the wave's first lane through readfirstlane -- the block pointer is wave-uniform, and only then does the
+    // compiler keep it in scalar registers: the KiB stores within the instruction's 4 KiB immediate range are issued as
+    // "scalar base + 32-bit lane offset", one 64-bit address computation less per step.  No measurable effect on the
+    // launch time, profiles/r03/store_addr.txt and the A/B beside it.)
+    if constexpr (OUT == 3)
+        obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + __builtin_amdgcn_readfirstlane(tid & ~63u)) * S;
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
     // block-uniform: lanes can be frozen (finished and waiting for reset -- also on an auto-reset handle whose lanes
     // were never reset, left out by reset(mask) or marked done by set_state: base.py:159-160 -- or out of range)

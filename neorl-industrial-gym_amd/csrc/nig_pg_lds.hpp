@@ -81,7 +81,10 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
     float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
     uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
     float *obs_row = nullptr;
-    if constexpr (OUT == 3) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S;
+    // (the wave's first lane through readfirstlane: the row pointer is wave-uniform, and only then does the compiler keep it
+    // in scalar registers; see rollout_body)
+    if constexpr (OUT == 3)
+        obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + __builtin_amdgcn_readfirstlane(tid & ~63u)) * S;
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
     const unsigned rd = (lane & 7u) * 8u + (lane >> 3);             // transposed read: image float4 64 j + rd = row-major float4 64 j + lane
 
@@ -259,6 +262,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) oo[lane + 64u * j] = v[j];
 #else
+                // two scalar bases 4 KiB apart: the instruction's immediate offset reaches 4 095 bytes
 #pragma unroll
                 for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, v[j]);
 #endif
