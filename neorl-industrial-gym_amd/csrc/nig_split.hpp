@@ -322,7 +322,11 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         if constexpr (OUT == 3) {
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
 #pragma unroll
+#ifdef NIG_DIAG_SPLIT_PLAINSTORE       // (diagnostic builds only: ordinary instead of streaming stores for the trajectory rows)
+            for (int k = 0; k < S / 4; ++k) oo[lane + 64u * k] = tr[k];
+#else
             for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, tr[k]);
+#endif
         }
         if constexpr (OUT == 2) {
 #pragma unroll
