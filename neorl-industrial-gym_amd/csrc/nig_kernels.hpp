@@ -352,24 +352,56 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
 // table is then shared by eight waves and two blocks = 16 waves fit a CU next to their reset images, so a
 // 262 144-lane batch is resident in ONE round instead of 1.33: 30 -> 24 us per step; small batches keep 256 to
 // spread over all CUs).
-template <class Env, bool PARITY, bool ACT64 = false, int BLK = 256>
-__global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVES)) step_kernel(const StepArgs p)
+// HELP (auto-reset handles of COOP_RESET envs in fast mode, batches that leave one wave per SIMD: launch_step): the block
+// is launched with 2 BLK threads.  Threads BLK .. 2 BLK - 1 are HELPER waves: helper h draws and builds the initial state
+// lane h would restart from if it finished in this step -- it depends on the lane's generator key only, not on the state
+// -- into LDS while the lane's own wave is still waiting for its loads and stepping; one block barrier later a finishing
+// lane just picks its row up.  At 65 536 lanes every launch has some wave with a finishing lane, so the launch always
+// paid the reset path behind its step (ballot, work list, two to eight generator blocks, their table look-ups -- a
+// third dependent memory round trip -- and the read-back: 1.6 of ChemicalReactor's 4.9 us per replayed launch,
+// profiles/r03/step_api_probe.txt); now that path runs beside the step instead of behind it, on issue slots the lone
+// wave of a SIMD leaves empty.  Same draw_init + init as reset_kernel and as the cooperative reset: same values.
+template <class Env, bool PARITY, bool ACT64 = false, int BLK = 256, bool HELP = false>
+__global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BLK / 256) * Env::STEP_WAVES)) step_kernel(const StepArgs p)
 {
-    constexpr int BLOCK = BLK;             // shadows the file-wide constant inside this kernel
+    constexpr int BLOCK = BLK;             // shadows the file-wide constant inside this kernel: LANES per block
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
     constexpr int NWAVE = BLOCK / 64;
     constexpr bool COOP = Env::COOP_RESET && !PARITY;          // wave-cooperative auto-reset (fast mode): coop_reset above
+    static_assert(!HELP || (COOP && !ACT64), "helper waves: fast-mode float32 steps of envs with a cooperative reset");
     using act_t = std::conditional_t<ACT64, double, float>;
     __shared__ unsigned short s_list[COOP ? 1 : BLOCK];
     __shared__ int s_cnt[COOP ? 1 : NWAVE];
-    __shared__ float s_img[COOP ? NWAVE * Env::RESET_ROWS * 64 : 1];
-    __shared__ unsigned char s_wlist[COOP ? BLOCK : 1];
+    __shared__ float s_img[COOP && !HELP ? NWAVE * Env::RESET_ROWS * 64 : 1];
+    __shared__ unsigned char s_wlist[COOP && !HELP ? BLOCK : 1];
+    __shared__ float s_new[HELP ? S * BLOCK : 1];              // [S][BLOCK]: the initial states the helpers prepared
 
-    const unsigned tid = threadIdx.x;
+    const bool helper = HELP && threadIdx.x >= (unsigned)BLOCK;
+    const unsigned tid = HELP ? (threadIdx.x & (unsigned)(BLOCK - 1)) : threadIdx.x;    // lane of the block (helper: the lane it works for)
     const uint32_t base = blockIdx.x * BLOCK;                  // block-uniform
     const bool in_range = base + tid < p.B;
     const uint32_t t_now = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
+    if constexpr (HELP) {
+        if (helper) {
+            __builtin_amdgcn_s_setprio(0);
+#ifdef NIG_DIAG_HELP_SKIP              // (diagnostic builds only, wrong restart states: what is left when the helpers cost nothing?)
+            if (false) {
+#else
+            if (in_range) {
+#endif
+                double rn[KR > 0 ? KR : 1];
+                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, NIG_PROBIT), rn);
+                float r0[S];
+                Env::init(rn, r0);
+#pragma unroll
+                for (int k = 0; k < S; ++k) s_new[k * BLOCK + tid] = r0[k];
+            }
+            __syncthreads();
+            return;
+        }
+        __builtin_amdgcn_s_setprio(2);
+    }
 
     // ---- one batch of loads -------------------------------------------------------------
     const uint32_t *ctr_row = p.ctr + base;
@@ -381,8 +413,13 @@ __global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVE
     act_t a[A];
     using nz_t = std::conditional_t<PARITY, double, typename Env::fast_noise_t>;   // injected draws are fp64
     nz_t nz[KSN];
+    double ret_prev = 0.0;                 // the running episode return (utils.py:99), read with the batch: a load behind the
+                                           // step's arithmetic would be one more memory round trip on the launch's critical path
     if (in_range) {
         ctr = ctr_row[tid];
+        // (without a branch: a conditional load would make the waitcnt pass drain it before the state loads are issued.  A
+        // handle without the tally has no return row; the always-present lifetime-violation row stands in, its value unused)
+        ret_prev = (p.tally ? p.ep_ret + base : reinterpret_cast<const double *>(p.life_viol + base))[tid];
 #pragma unroll
         for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld_state)[tid];
 #pragma unroll
@@ -406,7 +443,7 @@ __global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVE
     // when a lane looks up many normals per launch; an env with a couple of draws per step reads its
     // entries straight from the 12 KiB global table (L2-resident) -- staging 12 KiB per block plus a
     // block barrier costs more than two or three 16-byte loads per lane.
-    constexpr bool STAGE_TABLE = PARITY ? false : (KS > 4);
+    constexpr bool STAGE_TABLE = (PARITY || HELP) ? false : (KS > 4);      // (HELP: small batches; the helpers returned above)
     __shared__ float4 s_probit_[STAGE_TABLE ? 768 : 1];
     if constexpr (STAGE_TABLE) {
         for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
@@ -438,12 +475,15 @@ __global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVE
     if (active) {
         double ret = 0.0;
         if (p.tally) {                            // utils.py:99  episode_return += reward
-            const double prev = (p.ep_ret + base)[tid];
+            const double prev = ret_prev;
             if constexpr (Env::RET_F32 && !ACT64) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR, float32 rewards)
             else ret = prev + (double)res.reward;
         }
         if (done) {
-            (p.life_viol + base)[tid] += (long long)viol_ep;   // base.py:183 total_violations (never reset)
+            // base.py:183 total_violations (never reset): the lane's own counter, added to with a no-return atomic -- a
+            // load + add + store would put a dependent memory round trip behind the step in every launch that finishes a lane
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p.life_viol + base) + tid, (unsigned long long)viol_ep,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p.tally) {
                 if constexpr (tally_atomic<Env>::value) flush_tally_atomic(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en);
                 else flush_tally(p.tally + base + tid, p.ld, ret, step, viol_ep, res.ncrit, p.n_en);
@@ -476,11 +516,19 @@ __global__ void __launch_bounds__(BLK, (ACT64 ? 2 : (BLK / 256) * Env::STEP_WAVE
     }
 
     if constexpr (COOP) {
+        if constexpr (HELP) {
+            __syncthreads();                      // the helpers' rows are in LDS
+            if (need_reset) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) n[k] = s_new[k * BLOCK + tid];
+            }
+        } else {
         // every wave renews its own finishing lanes (all 64 lanes work, whatever their own state), then stores
         const unsigned long long m = __ballot(need_reset);
         if (m != 0ull)
             coop_reset<Env>(m, need_reset, tid & 63u, s_img + (tid >> 6) * (Env::RESET_ROWS * 64), s_wlist + (tid >> 6) * 64,
                             p.env0 + (uint64_t)(base + (tid & ~63u)), t_now, p.seed_lo, p.seed_hi, s_probit, n);
+        }
         if (active) {
             float *so = p.state + base;
 #pragma unroll
@@ -1638,8 +1686,17 @@ template <class Env>
 static void launch_step(const StepArgs &a, bool parity, unsigned grid, hipStream_t st)
 {
     constexpr int FB = Env::STEP_BLOCK;
-    if (parity) hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a);
-    else if (FB != BLOCK && a.B > 768u * BLOCK)       // more 256-thread blocks than are resident at once (3 per CU)
+    if (parity) { hipLaunchKernelGGL((step_kernel<Env, true>), dim3(grid), dim3(BLOCK), 0, st, a); return; }
+    if constexpr (Env::COOP_RESET) {
+        // auto-reset handles whose batch leaves one wave per SIMD (up to nig_tune(NIG_TUNE_SPLIT_BLOCKS) 256-lane blocks, default
+        // one per compute unit -- the knob of the three-wave rollout, the same regime): a helper wave per lane wave prepares
+        // the restart states beside the step (step_kernel, HELP)
+        if ((a.hflags & NIG_F_AUTORESET) != 0 && a.split_blocks != 0 && grid <= a.split_blocks) {
+            hipLaunchKernelGGL((step_kernel<Env, false, false, BLOCK, true>), dim3(grid), dim3(2 * BLOCK), 0, st, a);
+            return;
+        }
+    }
+    if (FB != BLOCK && a.B > 768u * BLOCK)            // more 256-thread blocks than are resident at once (3 per CU)
         hipLaunchKernelGGL((step_kernel<Env, false, false, FB>), dim3((a.B + FB - 1) / FB), dim3(FB), 0, st, a);
     else hipLaunchKernelGGL((step_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }

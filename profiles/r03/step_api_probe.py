@@ -14,7 +14,9 @@ import neorl_industrial_gym_amd as ni
 
 B, P, R = 65536, 250, 64
 out = {}
-for env_id in ("ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0"):
+ENVS = [e for e in ("ChemicalReactor-v0", "PowerGrid-v0", "RobotAssembly-v0") if len(sys.argv) < 2 or e.startswith(sys.argv[1])]
+for env_id in ENVS:
+    # (autoreset=0 is no baseline for the cost of auto-reset: finished lanes stay frozen, after a few hundred steps the launch is idle)
     for tally, autoreset in ((True, True), (False, True), (False, False)):
         env = ni.make_batched(env_id, B, autoreset=autoreset, tally=tally)
         ring = torch.empty(R, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
