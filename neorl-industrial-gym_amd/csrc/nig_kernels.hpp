@@ -415,28 +415,24 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
     nz_t nz[KSN];
     double ret_prev = 0.0;                 // the running episode return (utils.py:99), read with the batch: a load behind the
                                            // step's arithmetic would be one more memory round trip on the launch's critical path
-    if (in_range) {
-        ctr = ctr_row[tid];
-        // (without a branch: a conditional load would make the waitcnt pass drain it before the state loads are issued.  A
-        // handle without the tally has no return row; the always-present lifetime-violation row stands in, its value unused)
-        ret_prev = (p.tally ? p.ep_ret + base : reinterpret_cast<const double *>(p.life_viol + base))[tid];
+    // No branch around the loads: a lane beyond the batch reads lane 0's rows of its block (which exist) and is masked out
+    // below.  Loads inside a conditional block make the waitcnt pass wait for them where the block ends -- before the
+    // generator's arithmetic, which needs none of them -- instead of at their first use.
+    const unsigned li = in_range ? tid : 0u;
+    {
+        const uint32_t c_ld = ctr_row[li];
+        ctr = in_range ? c_ld : NIG_CTR_DONE;
+        // (the running return without a branch as well.  A handle without the tally has no return row; the always-present
+        // lifetime-violation row stands in, its value unused)
+        ret_prev = (p.tally ? p.ep_ret + base : reinterpret_cast<const double *>(p.life_viol + base))[li];
 #pragma unroll
-        for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld_state)[tid];
+        for (int k = 0; k < S; ++k) s[k] = (st_row + k * p.ld_state)[li];
 #pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = (act_row + k * p.ld_act)[tid];
+        for (int k = 0; k < A; ++k) a[k] = (act_row + k * p.ld_act)[li];
         if constexpr (PARITY && KS > 0) {
             const double *nz_row = p.step_noise + base;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) nz[k] = (nz_row + k * p.ld_noise)[tid];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < S; ++k) s[k] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = (act_t)0;
-        if constexpr (PARITY && KS > 0) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) nz[k] = 0.0;
+            for (int k = 0; k < KS; ++k) nz[k] = (nz_row + k * p.ld_noise)[li];
         }
     }
     // The generator's table: staged in LDS (only now: the state/action loads above are already in flight)
@@ -472,13 +468,13 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
     const bool autoreset = (p.hflags & NIG_F_AUTORESET) != 0;
     const bool need_reset = active && done && autoreset;
 
+    // utils.py:99  episode_return += reward.  Computed for every lane, used by the tally's: a use inside the conditional
+    // blocks below would let the compiler sink the LOAD of the running return down there, behind the step (one more round trip)
+    double ret;
+    if constexpr (Env::RET_F32 && !ACT64) ret = (double)((float)ret_prev + res.reward);   // float32 accumulation (CR, float32 rewards)
+    else ret = ret_prev + (double)res.reward;
+    asm volatile("" :: "v"(ret));                 // (a use the sinking pass cannot move the load past)
     if (active) {
-        double ret = 0.0;
-        if (p.tally) {                            // utils.py:99  episode_return += reward
-            const double prev = ret_prev;
-            if constexpr (Env::RET_F32 && !ACT64) ret = (double)((float)prev + res.reward);   // float32 accumulation (CR, float32 rewards)
-            else ret = prev + (double)res.reward;
-        }
         if (done) {
             // base.py:183 total_violations (never reset): the lane's own counter, added to with a no-return atomic -- a
             // load + add + store would put a dependent memory round trip behind the step in every launch that finishes a lane
