@@ -146,6 +146,18 @@ def test_split_form_robot_assembly_chunks_lengths_and_variants(ni, first_counter
         _same(a, b)
 
 
+def test_split_form_robot_assembly_long_run_at_full_size(ni):
+    """One block per compute unit (65 536 lanes, the size the form is for), 2 x 2 500 steps with the env's own episode
+    length: the three-slot rings wrap ~1 700 times under real contention; final state, counters, returns and tallies equal
+    the one-wave kernel's bit for bit (a protocol slip would show as a mismatch or as a hang of this call)."""
+    kw = dict(B=65536, chunks=[2500, 2500], outputs="none", R=64, max_steps=1000, name=RA)
+    a, ca = _run(ni, True, **kw)
+    b, cb = _run(ni, False, **kw)
+    assert ca == cb == 5000
+    _same(a, b)
+    assert float(a[-1][0].sum()) > 1e6         # millions of episodes finished and were tallied
+
+
 def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
     """Closed-loop rollouts (nig_rollout_policy) through one handle; returns every observable as CPU tensors."""
     if split is not None:                      # None: keep the knob the caller set
