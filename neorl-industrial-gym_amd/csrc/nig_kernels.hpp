@@ -385,16 +385,26 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
     const uint32_t base = blockIdx.x * BLOCK;                  // block-uniform
     const bool in_range = base + tid < p.B;
     const uint32_t t_now = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;     // (the pointer chase costs 0.03-0.05 us of the launch: measured with a build that skipped it)
+    // The generator's table: staged in LDS when a lane looks up many normals per launch; an env with a couple of draws
+    // per step reads its entries straight from the 12 KiB global table (L2-resident) -- staging 12 KiB per block plus a
+    // block barrier costs more than two or three 16-byte loads per lane.  With helper waves THEY stage it, first thing.
+    constexpr bool STAGE_TABLE = PARITY ? false : (KS > 4 || (HELP && KS > 0));
+    __shared__ float4 s_probit_[STAGE_TABLE ? 768 : 1];
+    const float4 *const s_probit = STAGE_TABLE ? s_probit_ : NIG_PROBIT;
     if constexpr (HELP) {
         if (helper) {
             __builtin_amdgcn_s_setprio(0);
+            if constexpr (STAGE_TABLE) {
+                for (int i_ = (int)tid; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
+                __syncthreads();
+            }
 #ifdef NIG_DIAG_HELP_SKIP              // (diagnostic builds only, wrong restart states: what is left when the helpers cost nothing?)
             if (false) {
 #else
             if (in_range) {
 #endif
                 double rn[KR > 0 ? KR : 1];
-                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, NIG_PROBIT), rn);
+                Env::draw_init(make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, s_probit), rn);
                 float r0[S];
                 Env::init(rn, r0);
 #pragma unroll
@@ -449,17 +459,13 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
             for (int k = 0; k < KS; ++k) nz[k] = (nz_row + k * p.ld_noise)[li];
         }
     }
-    // The generator's table: staged in LDS (only now: the state/action loads above are already in flight)
-    // when a lane looks up many normals per launch; an env with a couple of draws per step reads its
-    // entries straight from the 12 KiB global table (L2-resident) -- staging 12 KiB per block plus a
-    // block barrier costs more than two or three 16-byte loads per lane.
-    constexpr bool STAGE_TABLE = (PARITY || HELP) ? false : (KS > 4);      // (HELP: small batches; the helpers returned above)
-    __shared__ float4 s_probit_[STAGE_TABLE ? 768 : 1];
+    // the table is staged only now: the state / action loads above are already in flight
     if constexpr (STAGE_TABLE) {
-        for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
+        if constexpr (!HELP) {
+            for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
+        }
         __syncthreads();
     }
-    const float4 *s_probit = STAGE_TABLE ? s_probit_ : NIG_PROBIT;
     const bool active = in_range && !(ctr & NIG_CTR_DONE);     // base.py:159-160: finished lanes wait for reset
 
     const RngKey key = make_key(p.env0 + (uint64_t)(base + tid), t_now, p.seed_lo, p.seed_hi, s_probit);
