@@ -158,6 +158,32 @@ def test_split_form_robot_assembly_long_run_at_full_size(ni):
     assert float(a[-1][0].sum()) > 1e6         # millions of episodes finished and were tallied
 
 
+@pytest.mark.parametrize("name", [NAME, "PowerGrid-v0", RA])
+@pytest.mark.parametrize("B", [1024, 1000])
+def test_step_api_helper_waves_equal_the_plain_step_kernel(ni, name, B):
+    """The step API at one wave per SIMD launches step_kernel with HELPER waves (restart states, the generator's table and,
+    for PowerGrid, the tally flush prepared beside the step: csrc/nig_kernels.hpp step_kernel, HELP); the knob at 0 keeps
+    the plain kernel with its cooperative reset.  60 steps of 9-step episodes through both, whole blocks and a ragged
+    last block: every per-step reward / flag row, the final state, counters, lifetime violations, returns and tallies
+    are bit-identical."""
+    def run(knob):
+        ni.tune(split_blocks=knob)
+        env = ni.make_batched(name, B, seed=21, autoreset=True, tally=True, max_episode_steps=9)
+        env.reset()
+        act = torch.empty(env.action_dim, env.ld, dtype=torch.float32, device=env.device)
+        got = []
+        for t in range(1, 61):
+            env.fill_actions(500 + t, act)
+            env.step(act[:, :B], layout="soa")
+            got += [env.reward[:B].cpu().clone(), env.flags[:B].cpu().clone()]
+        got += [env.state_soa[:, :B].cpu(), env.ctr[:B].cpu(), env.life_viol[:B].cpu(), env.ep_return[:B].cpu(), env.tally[:, :B].cpu()]
+        env.close()
+        return got
+    a, b = run(256), run(0)
+    _same(a, b)
+    assert float(a[-1][0].sum()) > B               # every lane finished several episodes
+
+
 def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
     """Closed-loop rollouts (nig_rollout_policy) through one handle; returns every observable as CPU tensors."""
     if split is not None:                      # None: keep the knob the caller set
