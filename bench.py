@@ -248,7 +248,11 @@ def rollout_kernel_name(wl):
     # everything, with the knob at 2^30 or more) on the register-resident kernel
     wide_min = wl.ni.tune()["wide_min_blocks"]
     if wl.key == "pg" and wide_min < (1 << 30) and wl.B >= 256:
-        return "rollout_wide_kernel<PowerGrid,%d,%d>" % (out, 512 if (wl.B // 512 >= max(1, wide_min)) else 256)
+        if wl.B // 512 >= max(1, wide_min):
+            return "rollout_wide_kernel<PowerGrid,%d,512>" % out
+        if per_round and blocks <= per_round:     # at most one 256-lane block per compute unit: stepping + producer wave per 64 lanes
+            return "rollout_pg_pair_kernel<%d>" % out
+        return "rollout_wide_kernel<PowerGrid,%d,256>" % out
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 
 

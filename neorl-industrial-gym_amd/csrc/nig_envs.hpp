@@ -274,6 +274,7 @@ struct PowerGrid {
     static constexpr int ROLLOUT_WAVES = 2;       // same, for the fused rollout kernels
     // Big auto-reset batches run the LDS-resident form (nig_pg_lds.hpp): 512-thread blocks, four waves per SIMD.
     static constexpr int WIDE_ROLLOUT_BLOCK = 512, WIDE_ROLLOUT_WAVES = 2;
+    static constexpr bool PAIR_ROLLOUT = true;     // batches of at most one 256-lane block per CU: stepping + producer wave per 64 lanes (nig_pg_lds.hpp)
     static constexpr bool TALLY_ATOMIC = false;   // 18 % of the lanes finish every step: see tally_atomic (nig_kernels.hpp)
     using reward_t = double;  // float(total_reward), :177
     __device__ static constexpr float act_low(int) { return -1.0f; }

@@ -982,6 +982,7 @@ template <class E, class = void> struct wide_rollout : std::integral_constant<in
 template <class E> struct wide_rollout<E, std::void_t<decltype(E::WIDE_ROLLOUT_BLOCK)>> : std::integral_constant<int, E::WIDE_ROLLOUT_BLOCK> {};
 
 }  // namespace nig
+#include "nig_ring.hpp"
 #include "nig_pg_lds.hpp"
 namespace nig {
 template <class Env, int OUT, int BLK>
@@ -1787,6 +1788,21 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
                 default: hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
                 }
                 first = n_wide * (WB / BLOCK);
+            }
+            if constexpr (pair_rollout<Env>::value) {
+                // a batch that would leave one wave on every SIMD (at most nig_tune(NIG_TUNE_SPLIT_BLOCKS) 256-lane blocks,
+                // default one per compute unit): the paired form -- a producer wave draws the step's normals beside every
+                // stepping wave (rollout_pg_pair_kernel, nig_pg_lds.hpp)
+                if (first == 0 && n_full > 0 && q.s.split_blocks != 0 && n_full <= q.s.split_blocks) {
+                    r.block0 = 0;
+                    switch (out_mode) {
+                    case 0: hipLaunchKernelGGL((rollout_pg_pair_kernel<0>), dim3(n_full), dim3(512), 0, st, r); break;
+                    case 1: hipLaunchKernelGGL((rollout_pg_pair_kernel<1>), dim3(n_full), dim3(512), 0, st, r); break;
+                    case 2: hipLaunchKernelGGL((rollout_pg_pair_kernel<2>), dim3(n_full), dim3(512), 0, st, r); break;
+                    default: hipLaunchKernelGGL((rollout_pg_pair_kernel<3>), dim3(n_full), dim3(512), 0, st, r); break;
+                    }
+                    first = n_full;
+                }
             }
             if (n_full > first) {
                 r.block0 = first;

@@ -37,17 +37,74 @@ struct PgLds {
     static constexpr int BYTES = OFF_WLIST + NWAVE * 64;
 };
 
-template <int OUT, int BLK>
+// The PAIRED form (rollout_pg_pair_kernel below; batches of at most one 256-lane block per compute unit, where the body
+// above would leave a single wave on every SIMD): the block carries a second set of four waves, the PRODUCERS.  Producer w
+// draws the step's 23 normals for the 64 lanes of stepping wave w -- six Philox blocks and 23 table transforms, ~510 of the
+// step's ~1 090 vector instructions, all a function of the lane's generator key alone -- one or two steps ahead into a
+// two-slot ring in LDS; the stepping wave reads them as six float4 per step where it used to compute them.  The two waves
+// of a pair share a SIMD (a block's waves go round the four SIMDs), so the SIMD issues from two instruction streams
+// instead of one.  Ring protocol, counters and fences: nig_ring.hpp.  The normals pass through LDS as the floats they
+// are: same bits as the one-wave form.  65 536 lanes x 250 steps: 822 -> 688 us with full outputs, 810 -> 655 us with
+// reward + flags (profiles/r03/pg_pair_ab.txt); the stepping wave is what bounds it then (a chain of LDS round trips
+// through its state image: ~10 cycles per instruction) -- TWO producers per stepping wave, three generator blocks each,
+// were no faster (711 / 676 us).
+struct PgPairLds {
+    static constexpr int K = 2;                                   // ring slots (steps) per pair
+    static constexpr int SLOT_V4 = 6 * 64;                        // float4 per slot: [generator block][lane]
+    static constexpr int OFF_NZ = (PgLds<256>::BYTES + 15) / 16 * 16;
+    static constexpr int OFF_SYNC = OFF_NZ + 4 * K * SLOT_V4 * 16;     // uint32 [4 pairs][4]: {produced, consumed}
+    static constexpr int BYTES = OFF_SYNC + 4 * 16;
+    static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+};
+
+// producer wave `wave` (0-3) of the block: lanes base + 64 wave .. + 63, local steps [0, n)
+__device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uint32_t base, unsigned char *smem, const unsigned wave, const unsigned lane)
+{
+    using L = PgPairLds;
+    const float4 *const s_probit = reinterpret_cast<const float4 *>(smem + PgLds<256>::OFF_PROBIT);
+    v4f *const ring = reinterpret_cast<v4f *>(smem + L::OFF_NZ) + wave * (L::K * L::SLOT_V4);
+    lds_u32_t *const sync = (lds_u32_t *)(smem + L::OFF_SYNC) + wave * 4;
+    const StepArgs &p = q.s;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off + (uint32_t)q.it0;      // local step i uses t_base + i + 1
+    const uint64_t gi = p.env0 + (uint64_t)(base + wave * 64u + lane);
+    const int n = q.n_steps - q.it0;
+    uint32_t freed = 0u;                                           // slots the stepping wave is known to be done with
+    for (int i = 0; i < n; ++i) {
+        const RngKey key = make_key(gi, t_base + (uint32_t)i + 1u, p.seed_lo, p.seed_hi, s_probit);
+        v4f z[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                              // draw_step: blocks 0-5 of the step stream, words in order
+            const u32x4 x = key.block(STREAM_STEP + (uint32_t)j);
+            const ProbitFetch f0 = probit_fetch(x.x, s_probit), f1 = probit_fetch(x.y, s_probit), f2 = probit_fetch(x.z, s_probit);
+            v4f w = {probit_eval(f0), probit_eval(f1), probit_eval(f2), 0.0f};
+            if (j < 5) w.w = probit_eval(probit_fetch(x.w, s_probit));     // z[23] does not exist
+            z[j] = w;
+        }
+        if (freed + (uint32_t)L::K < (uint32_t)i + 1u) freed = split_wait(sync + 1, (uint32_t)(i + 1 - L::K));   // the slot's previous use
+        v4f *slot = ring + (i & (L::K - 1)) * L::SLOT_V4;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) slot[64 * j + lane] = z[j];
+        split_post(sync + 0, (uint32_t)i + 1u, lane);
+    }
+}
+
+template <int OUT, int BLK, bool PROD = false>
 __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
 {
     using Env = PowerGrid;
     constexpr int S = Env::S, A = Env::A;
     using Lds = PgLds<BLK>;
+    static_assert(!PROD || BLK == 256, "the paired form runs 256-lane blocks");
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
-    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLK) s_probit[i_] = NIG_PROBIT[i_];
-    __syncthreads();
+    if constexpr (!PROD) {                         // (paired form: the kernel staged the table with all its waves)
+        for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLK) s_probit[i_] = NIG_PROBIT[i_];
+        __syncthreads();
+    }
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    [[maybe_unused]] const v4f *const nz_ring = reinterpret_cast<const v4f *>(smem + PgPairLds::OFF_NZ) + wave * (PgPairLds::K * PgPairLds::SLOT_V4);
+    [[maybe_unused]] lds_u32_t *const nz_sync = (lds_u32_t *)(smem + PgPairLds::OFF_SYNC) + wave * 4;
+    [[maybe_unused]] uint32_t nz_seen = 0u;
     v4f *const img = reinterpret_cast<v4f *>(smem + Lds::OFF_IMG) + wave * 512;
     v4f *const mine = img + (lane >> 3) * 64 + (lane & 7u);         // group g of this lane: mine[8 g]
     float *const imgf = reinterpret_cast<float *>(img);
@@ -142,7 +199,19 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             act_next = (slot == 0) ? ring : act_next + q.slot_stride;
             __builtin_amdgcn_sched_barrier(0);
             // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------
-            u32x4 x = key.block(STREAM_STEP);
+            [[maybe_unused]] const int itl = it - q.it0;                 // local step: the producer's slot index
+            [[maybe_unused]] const v4f *const nzs = nz_ring + (itl & (PgPairLds::K - 1)) * PgPairLds::SLOT_V4;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if constexpr (PROD) {
+                if (nz_seen < (uint32_t)itl + 1u) nz_seen = split_wait(nz_sync + 0, (uint32_t)itl + 1u);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const v4f zq = nzs[64 * j + lane];
+                    v[4 * j + 0] = v[4 * j + 0] + 0.005f * zq.x; v[4 * j + 1] = v[4 * j + 1] + 0.005f * zq.y;   // :136-137
+                    v[4 * j + 2] = v[4 * j + 2] + 0.005f * zq.z; v[4 * j + 3] = v[4 * j + 3] + 0.005f * zq.w;
+                }
+            } else {
+            x = key.block(STREAM_STEP);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 ProbitFetch f[4];
@@ -157,6 +226,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                 // scratch -- and a scratch reload drains vmcnt, i.e. every streaming store of the step.  The other waves
                 // of the SIMD cover the table latency; the load / line-flow phase below does overlap.)
                 x = key.block(STREAM_STEP + (uint32_t)(j + 1));
+            }
             }
             {
                 v4f w0 = {n0, v[0], v[1], v[2]}, w1 = {v[3], v[4], v[5], v[6]}, w2 = {v[7], ngen[0], ngen[1], ngen[2]};
@@ -189,14 +259,25 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
 #pragma unroll
             for (int j = 2; j < 6; ++j) {
                 ProbitFetch f[4];
+                v4f zq = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (PROD) {
+                    zq = nzs[64 * j + lane];
+                    if (j == 5) split_post(nz_sync + 1, (uint32_t)itl + 1u, lane);     // (DS order: the reads above execute before this write)
+                } else {
                 f[0] = probit_fetch(x.x, s_probit); f[1] = probit_fetch(x.y, s_probit); f[2] = probit_fetch(x.z, s_probit);
                 if (j < 5) f[3] = probit_fetch(x.w, s_probit);               // z[23] does not exist
                 if (j < 5) x = key.block(STREAM_STEP + (uint32_t)(j + 1));
+                }
+                // the step's normals of this phase: transformed here (one-wave form) or read from the producer's slot
+                auto zn = [&](int c) __attribute__((always_inline)) -> float {
+                    if constexpr (PROD) return c == 0 ? zq.x : c == 1 ? zq.y : c == 2 ? zq.z : zq.w;
+                    else return probit_eval(f[c]);
+                };
                 asm volatile("" ::: "memory");                               // the groups are read again HERE, not kept from the top
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == 2) {                      // load[0..3]: group 4 = {gen7, load0, load1, load2}, load3 = group 5 .x
                     const v4f h4 = mine[32], h5 = mine[40];
-                    float l[4] = {h4.y + probit_eval(f[0]), h4.z + probit_eval(f[1]), h4.w + probit_eval(f[2]), h5.x + probit_eval(f[3])};   // :140
+                    float l[4] = {h4.y + zn(0), h4.z + zn(1), h4.w + zn(2), h5.x + zn(3)};   // :140
 #pragma unroll
                     for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];                                   // :141
                     v4f w4 = {ngen7, l[0], l[1], l[2]};
@@ -208,7 +289,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     }
                 } else if (j == 3) {               // load[4..7]: group 5 = {load3 .. load6}, load7 = group 6 .x
                     const v4f h5 = mine[40], h6 = mine[48];
-                    float l[4] = {h5.y + probit_eval(f[0]), h5.z + probit_eval(f[1]), h5.w + probit_eval(f[2]), h6.x + probit_eval(f[3])};
+                    float l[4] = {h5.y + zn(0), h5.z + zn(1), h5.w + zn(2), h6.x + zn(3)};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];
                     v4f w5 = {l7, l[0], l[1], l[2]};
@@ -221,8 +302,8 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     l7 = l[3];                     // load7'
                 } else if (j == 4) {               // flows[0..3]: group 6 = {load7, flow0, flow1, flow2}, flow3 = group 7 .x
                     const v4f h6 = mine[48], h7 = mine[56];
-                    const float fl[4] = {h6.y + 2.0f * probit_eval(f[0]), h6.z + 2.0f * probit_eval(f[1]),
-                                         h6.w + 2.0f * probit_eval(f[2]), h7.x + 2.0f * probit_eval(f[3])};          // :144
+                    const float fl[4] = {h6.y + 2.0f * zn(0), h6.z + 2.0f * zn(1),
+                                         h6.w + 2.0f * zn(2), h7.x + 2.0f * zn(3)};          // :144
                     v4f w6 = {l7, fl[0], fl[1], fl[2]};
                     mine[48] = w6;
                     if constexpr (OUT == 2) {
@@ -233,7 +314,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     l7 = fl[3];                    // flow3'
                 } else {                           // flows[4..6]: group 7 = {flow3 .. flow6}
                     const v4f h7 = mine[56];
-                    const float fl[3] = {h7.y + 2.0f * probit_eval(f[0]), h7.z + 2.0f * probit_eval(f[1]), h7.w + 2.0f * probit_eval(f[2])};
+                    const float fl[3] = {h7.y + 2.0f * zn(0), h7.z + 2.0f * zn(1), h7.w + 2.0f * zn(2)};
                     v4f w7 = {l7, fl[0], fl[1], fl[2]};
                     mine[56] = w7;
                     if constexpr (OUT == 2) {
@@ -262,7 +343,6 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) oo[lane + 64u * j] = v[j];
 #else
-                // two scalar bases 4 KiB apart: the instruction's immediate offset reaches 4 095 bytes
 #pragma unroll
                 for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, v[j]);
 #endif
@@ -319,5 +399,24 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
     }
 }
+
+// The paired form's kernel: 256 lanes per block, 512 threads -- waves 0-3 step (pg_lds_rollout_body, PROD), waves 4-7
+// produce their normals (pg_pair_producer).  q.block0 counts 256-lane blocks.  One block per compute unit is resident.
+template <int OUT>
+__global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutArgs q)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PgPairLds::BYTES];
+    float4 *const s_probit = reinterpret_cast<float4 *>(smem + PgLds<256>::OFF_PROBIT);
+    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += 512) s_probit[i_] = NIG_PROBIT[i_];
+    if (threadIdx.x < 16u) reinterpret_cast<uint32_t *>(smem + PgPairLds::OFF_SYNC)[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = (blockIdx.x + q.block0) * 256u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4u) pg_pair_producer(q, base, smem, wave - 4u, threadIdx.x & 63u);
+    else pg_lds_rollout_body<OUT, 256, true>(q, base, smem);
+}
+
+template <class E, class = void> struct pair_rollout : std::false_type {};
+template <class E> struct pair_rollout<E, std::void_t<decltype(E::PAIR_ROLLOUT)>> : std::bool_constant<E::PAIR_ROLLOUT> {};
 
 }  // namespace nig

@@ -60,8 +60,11 @@ def _pg_ring(env, R, t0=70):
 
 def _pg_run(ni, wide, B, chunks, outputs, R, max_steps=1000, seed=11, tally=True, env_index0=0, cmask=None, t0=70):
     """wide: True = the LDS-resident body, whole 512-lane blocks in the wide form; an int = the knob value (256: the
-    default -- a small batch then runs the same body in 256-lane blocks); False = rollout_kernel only."""
-    ni.tune(wide_min_blocks=NEVER if wide is False else (1 if wide is True else int(wide)))
+    default -- a small batch then runs the same body in 256-lane blocks); "pair" = default knobs: a batch of at most one
+    256-lane block per compute unit runs the paired form (producer waves, rollout_pg_pair_kernel); False = rollout_kernel
+    only."""
+    ni.tune(wide_min_blocks=NEVER if wide is False else (1 if wide is True else 256 if wide == "pair" else int(wide)),
+            split_blocks=256 if wide == "pair" else 0)
     env = ni.make_batched(PG, B, seed=seed, autoreset=True, tally=tally, max_episode_steps=max_steps, env_index0=env_index0)
     if cmask is not None:
         env.set_constraint_mask(cmask)
@@ -104,15 +107,16 @@ def _same(a, b):
 @pytest.fixture()
 def wide_knob(ni):
     yield
-    ni.tune(wide_min_blocks=256)
+    ni.tune(wide_min_blocks=256, split_blocks=256)
 
 
 @pytest.mark.parametrize("outputs", ["none", "min", "last", "soa", "aos"])
-@pytest.mark.parametrize("knob", [True, 256])
+@pytest.mark.parametrize("knob", [True, 256, "pair"])
 def test_pg_lds_rollout_equals_register_rollout(ni, wide_knob, outputs, knob):
     """Three wide blocks + one whole 256-lane block + a ragged tail.  knob True: the wide (512-lane) form runs the first
-    1536 lanes, the 256-lane form of the same LDS-resident body the next block, rollout_kernel the ragged tail; knob 256
-    (the default): the batch is below the wide threshold, so all seven whole blocks run the 256-lane form.  Either way
+    1536 lanes, the 256-lane form of the same LDS-resident body the next block, rollout_kernel the ragged tail; knob 256:
+    the batch is below the wide threshold, so all seven whole blocks run the 256-lane form; "pair" (the defaults): those
+    seven blocks run the paired form, a producer wave drawing the normals of every stepping wave.  Either way
     every observable equals the same batch entirely on the register-resident kernel, over several launches (ring
     wrap-around, odd step counts)."""
     B = 3 * 512 + 256 + 37
@@ -125,9 +129,10 @@ def test_pg_lds_rollout_short_episodes_and_masks(ni, wide_knob):
     """Truncation every 3 steps (every lane resets again and again), a constraint mask, a lane offset, no tally."""
     B = 4 * 512
     for kw in (dict(max_steps=3), dict(cmask=0b101), dict(env_index0=(1 << 33) + 12345), dict(tally=False)):
-        a = _pg_run(ni, True, B, [9, 4], "aos", R=4, **kw)
         b = _pg_run(ni, False, B, [9, 4], "aos", R=4, **kw)
-        _same(a, b)
+        for form in (True, "pair"):
+            a = _pg_run(ni, form, B, [9, 4], "aos", R=4, **kw)
+            _same(a, b)
 
 
 def test_pg_lds_rollout_bit_identical_to_oracle_at_baseline_size(ni, wide_knob, oracle):
@@ -158,6 +163,38 @@ def test_pg_lds_rollout_bit_identical_to_oracle_at_baseline_size(ni, wide_knob, 
     keep = ((fl[T - 1, :B] & L.FLAG_DID_RESET) == 0).cpu().numpy()
     last = obs[T - 1].cpu().numpy()
     assert keep.sum() > B // 2 and np.array_equal(last[keep].view(np.uint32), got[keep].view(np.uint32))
+    env.close()
+
+
+def test_pg_paired_form_at_one_block_per_compute_unit_against_oracle(ni, wide_knob, oracle):
+    """The paired form at the size it is for: 65 536 PowerGrid lanes = one 256-lane block with its four producer waves on
+    every compute unit, 2 x 150 + 1 fused steps (the two-slot noise rings wrap 150 times under real contention; a protocol
+    slip would show as a mismatch or a hang of this call).  bench.py's naming rule says which kernel ran; final state,
+    step counters, violation / critical / episode totals equal the CPU oracle's, bit for bit."""
+    import types
+    import bench
+    B, T = 65536, 301
+    ni.tune(wide_min_blocks=256, split_blocks=256)
+    assert bench.rollout_kernel_name(types.SimpleNamespace(key="pg", B=B, outputs="min", ni=ni)) == "rollout_pg_pair_kernel<1>"
+    env = ni.make_batched(PG, B, autoreset=True, tally=True)
+    ring = torch.empty(T, env.action_dim, env.ld, dtype=torch.float32, device=env.device)
+    for s in range(T):
+        env.fill_actions(1 + s, ring[s])
+    fl = torch.zeros(T, env.ld, dtype=torch.int32, device=env.device)
+    rw = torch.zeros(T, env.ld, dtype=torch.float32, device=env.device)
+    env.reset()
+    env.rollout(150, ring[:150], rw[:150], fl[:150])
+    env.rollout(150, ring[150:300], rw[150:300], fl[150:300])
+    env.rollout(1, ring[300:], rw[300:], fl[300:])
+    torch.cuda.synchronize()
+    st, sc, total, _ = oracle.rollout("pg", B, T, flavor=oracle.MATH_POLY, nthreads=16)
+    assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32), st.view(np.uint32))
+    assert np.array_equal(env.current_step.cpu().numpy(), sc)
+    L = ni._lib
+    nv = int(((fl[:, :B] >> L.FLAG_NVIOL_SHIFT) & 3).sum().item())
+    nc = int(((fl[:, :B] >> L.FLAG_NCRIT_SHIFT) & 3).sum().item())
+    assert (nv, nc) == (total.violations, total.critical)
+    assert int(env.tally[L.T_EPISODES].sum().item()) == total.episodes
     env.close()
 
 

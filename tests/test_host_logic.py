@@ -304,7 +304,8 @@ def test_bench_names_the_kernel_the_library_launches():
         assert name("cr", 65536 + 100).startswith("split_")          # whole blocks in this form, the ragged last block in a one-wave launch
         assert name("cr", 200).startswith("rollout_kernel<")          # no whole block at all
         assert name("pg", 262144) == "rollout_wide_kernel<PowerGrid,3,512>"      # >= 256 blocks of 512 lanes: the LDS-resident form
-        assert name("pg", 65536) == "rollout_wide_kernel<PowerGrid,3,256>"      # 128 wide blocks: below the threshold, 256-lane blocks of the same body
+        assert name("pg", 65536) == "rollout_pg_pair_kernel<3>"                 # one 256-lane block per compute unit: the paired form (producer waves)
+        assert name("pg", 98304) == "rollout_wide_kernel<PowerGrid,3,256>"      # 192 wide blocks: below the wide threshold, more than one round of pairs
         assert name("pg", 100) == "rollout_kernel<PowerGrid,3>"                 # no whole block
         assert name("ra", 262144) == "rollout_kernel<RobotAssembly,3>"          # more than one round: lanes fill the SIMDs
         assert name("ra", 65536) == "split_rollout_kernel<RobotAssembly,3,4>" and name("ra", 1024, "min") == "split_rollout_kernel<RobotAssembly,1,4>"
@@ -312,6 +313,8 @@ def test_bench_names_the_kernel_the_library_launches():
         ni.tune(split_blocks=0, wide_min_blocks=1 << 30)
         assert name("cr", 65536).startswith("rollout_kernel<") and name("pg", 262144) == "rollout_kernel<PowerGrid,3>"
         assert name("ra", 65536) == "rollout_kernel<RobotAssembly,3>"
+        ni.tune(split_blocks=0, wide_min_blocks=256)
+        assert name("pg", 65536) == "rollout_wide_kernel<PowerGrid,3,256>"
     finally:
         ni.tune(split_blocks=before, wide_min_blocks=256)
 
