@@ -17,7 +17,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(x in r['Kernel_Name'] for x in ('rollout_kernel', 'rollout_pair', 'step_kernel', 'split_rollout', 'rollout_wide', 'mixed_rollout', 'rollout_mlp', 'split_policy', 'rollout_policy')):
+    if any(x in r['Kernel_Name'] for x in ('rollout_kernel', 'rollout_pair', 'rollout_pg_pair', 'step_kernel', 'split_rollout', 'rollout_wide', 'mixed_rollout', 'rollout_mlp', 'split_policy', 'rollout_policy')):
         acc[r['Kernel_Name'][:80]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)
