@@ -146,7 +146,9 @@ const char *nig_last_error(void);
  *                           handles on which no lane can be frozen); default = the compute units of the handle's
  *                           device (one wide block per compute unit); smaller batches run the same LDS-resident
  *                           body in 256-lane blocks; 2^30 or more = never use that body (rollout_kernel only).  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.
- * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / negative value); nig_tune_get returns the value or -1. */
+ * A value of -1 removes an explicit setting: every handle is back on its own device's default (tests restore with it).
+ * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / value below -1); nig_tune_get returns the value in effect
+ * for the device of the latest handle, or -1 for an unknown key. */
 enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1 };
 int nig_tune(int32_t key, int64_t value);
 int64_t nig_tune_get(int32_t key);
@@ -295,6 +297,30 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
                 int64_t slot_stride, int32_t ring_len, float *reward_out, uint32_t *flags_out,
                 int64_t out_stride, float *obs_out, int64_t ld_obs, int64_t obs_step_stride,
                 void *stream);
+
+/*
+ * nig_rollout with the reference's RECORDED random draws in place of the generator's -- parity mode of the fused
+ * kernels: the same kernel forms nig_rollout selects for the handle and batch (three-wave, LDS-resident wide / paired,
+ * one-wave; same thresholds, same launch shapes) run base.py:157-213 end to end on the values np.random returned
+ * inside _dynamics (chemical_reactor.py:149,159; power_grid.py:136-144) and _get_initial_state
+ * (chemical_reactor.py:89-107, power_grid.py:90-110, robot_assembly.py:113-137).  One row set per call step, as
+ * nig_step's parity arguments:
+ *   step_noise   double, row set of call step k at step_noise + k*step_noise_stride, laid out [k_step][ld_noise]
+ *                (NULL for an env without step noise)
+ *   reset_noise  double, row set of call step k at reset_noise + k*reset_noise_stride, laid out [k_reset][ld_noise]:
+ *                the initial-state draws of a lane whose episode ends in call step k (auto-reset handles; a finishing
+ *                lane restarts from _get_initial_state on them, evaluated per lane)
+ * action_ring must hold every step of the call (ring_len >= n_steps).  Outputs as nig_rollout with the row-major
+ * trajectory (obs_out float [n_steps][B][S], obs_step_stride 0 or >= S*B): reward_out, flags_out and obs_out are all
+ * required.  ChemicalReactor, PowerGrid, RobotAssembly only (NIG_ERR_UNSUPPORTED otherwise): the envs upstream can run.
+ * Exists for tests/test_gpu_noise_rollout.py (tests/golden/<env>_g3.npz through every form); the arithmetic outside
+ * the replaced draws is the code nig_rollout runs.
+ */
+int nig_rollout_noise(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act,
+                      int64_t slot_stride, int32_t ring_len, const double *step_noise, int64_t step_noise_stride,
+                      const double *reset_noise, int64_t reset_noise_stride, int64_t ld_noise,
+                      float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                      float *obs_out, int64_t obs_step_stride, void *stream);
 
 /*
  * Closed-loop rollouts with an on-device policy ("nig-policy-v1").  The policy

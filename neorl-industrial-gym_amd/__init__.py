@@ -25,7 +25,8 @@ from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
 def tune(split_blocks=None, wide_min_blocks=None):
     """Process-wide kernel-selection knobs of libnig (include/nig.h nig_tune); results never depend on them.
     split_blocks: largest batch, in 256-lane blocks, that rollout() runs in the three-wave form (0 = never).
-    wide_min_blocks: smallest batch, in 512-lane blocks, that rollout() runs in the wide form (PowerGrid / RobotAssembly).
+    wide_min_blocks: smallest batch, in 512-lane blocks, that rollout() runs in the wide form (PowerGrid).
+    -1 removes an explicit setting (back to the per-device default: the device's compute-unit count).
     Returns the current settings."""
     L = _lib.lib()
     if split_blocks is not None:

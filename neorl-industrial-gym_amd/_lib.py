@@ -32,7 +32,7 @@ SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",
     "nig_create", "nig_destroy", "nig_get_layout", "nig_workspace", "nig_get_counter", "nig_set_counter",
     "nig_set_constraint_mask", "nig_reset", "nig_step", "nig_fill_actions", "nig_set_state", "nig_get_state",
-    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
+    "nig_get_safety_metrics", "nig_reduce_tally", "nig_plan_create", "nig_plan_launch", "nig_plan_destroy", "nig_rollout", "nig_rollout_noise", "nig_bind_state", "nig_set_policy", "nig_rollout_policy", "nig_set_mlp_policy", "nig_rollout_mlp", "nig_reset_host", "nig_step_host",
     "nig_step64", "nig_step_host64", "nig_reduce_metrics",
     "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
     "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step", "nig_rollout_mixed_obs", "nig_mixed_rollout_obs",
@@ -141,6 +141,7 @@ def lib():
     L.nig_reduce_metrics.argtypes = [C.POINTER(vp), i32, vp, vp, i64, vp, vp]
     L.nig_step64.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.nig_rollout.argtypes = [vp, i32, vp, i64, i64, i32, vp, vp, i64, vp, i64, i64, vp]
+    L.nig_rollout_noise.argtypes = [vp, i32, vp, i64, i64, i32, vp, i64, vp, i64, i64, vp, vp, i64, vp, i64, vp]
     L.nig_create_mixed.argtypes = [i32, C.POINTER(i32), C.POINTER(i64), C.c_int, u64, u64, u32, C.POINTER(vp)]
     L.nig_mixed_destroy.argtypes = [vp]
     L.nig_mixed_get_info.argtypes = [vp, C.POINTER(MixedInfo)]

@@ -339,6 +339,39 @@ class BatchedIndustrialEnv:
             _lib.check(self._L.nig_rollout(self._h, int(n_steps), C.c_void_p(action_ring.data_ptr()), ld,
                                            action_ring.stride(0), R, rp, fp, rs or fs, op, ldo, so, self._stream()))
 
+    def rollout_noise(self, n_steps: int, action_ring: torch.Tensor, step_noise: Optional[torch.Tensor],
+                      reset_noise: Optional[torch.Tensor], reward_out: torch.Tensor, flags_out: torch.Tensor,
+                      obs_out: torch.Tensor):
+        """rollout() on the reference's RECORDED draws (nig_rollout_noise): the same kernel form the batch would
+        take, with np.random's values injected.  action_ring float32 [n_steps, A, ld]; step_noise float64
+        [n_steps, k_step, ld] (None for an env without step noise); reset_noise float64 [n_steps, k_reset, ld]
+        (auto-reset handles: the initial-state draws of a lane that finishes in that step); reward_out /
+        flags_out [n_steps, >=B]; obs_out float32 contiguous [n_steps, B, S]."""
+        assert action_ring.dtype == torch.float32 and action_ring.dim() == 3 and action_ring.stride(2) == 1
+        assert action_ring.shape[0] >= n_steps and action_ring.shape[1] == self.action_dim
+        ldn = 0
+
+        def nz(t):
+            nonlocal ldn
+            if t is None:
+                return None, 0
+            assert t.dtype == torch.float64 and t.dim() == 3 and t.stride(2) == 1 and t.shape[0] >= n_steps
+            assert ldn in (0, t.stride(1)), "step_noise and reset_noise share their row pitch"
+            ldn = t.stride(1)
+            return C.c_void_p(t.data_ptr()), t.stride(0)
+
+        sp, ss = nz(step_noise)
+        rp, rs = nz(reset_noise)
+        assert reward_out.dtype == torch.float32 and flags_out.dtype == torch.int32 and reward_out.dim() == 2
+        assert reward_out.stride(0) == flags_out.stride(0) and reward_out.shape[0] >= n_steps
+        assert obs_out.dtype == torch.float32 and obs_out.is_contiguous() and obs_out.shape[1:] == (self.batch, self.state_dim)
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._L.nig_rollout_noise(
+                self._h, int(n_steps), C.c_void_p(action_ring.data_ptr()), action_ring.stride(1), action_ring.stride(0),
+                action_ring.shape[0], sp, ss, rp, rs, ldn, C.c_void_p(reward_out.data_ptr()),
+                C.c_void_p(flags_out.data_ptr()), reward_out.stride(0), C.c_void_p(obs_out.data_ptr()), obs_out.stride(0),
+                self._stream()))
+
     # ------------------------------------------------------------------
     def set_policy(self, policy):
         """Install an on-device policy (policies.DevicePolicy) for rollout_policy()."""

@@ -282,9 +282,10 @@ const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)
 {
-    if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < 0 || value >= (int64_t)nig::TUNE_UNSET)
+    if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < -1 || value >= (int64_t)nig::TUNE_UNSET)
         return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
-    (key == NIG_TUNE_WIDE_MIN_BLOCKS ? nig::g_wide_override : nig::g_split_override).store((unsigned)value, std::memory_order_relaxed);
+    // -1 = back to "no explicit setting": every handle uses its own device's default again
+    (key == NIG_TUNE_WIDE_MIN_BLOCKS ? nig::g_wide_override : nig::g_split_override).store(value < 0 ? nig::TUNE_UNSET : (unsigned)value, std::memory_order_relaxed);
     return NIG_OK;
 }
 int64_t nig_tune_get(int32_t key)
@@ -535,9 +536,10 @@ int nig_step64(nig_handle *h, const double *actions, int64_t ld_act, const doubl
     return NIG_OK;
 }
 
-int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
-                int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride,
-                float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
+static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
+                        int32_t ring_len, const double *step_noise, int64_t step_noise_stride, const double *reset_noise,
+                        int64_t reset_noise_stride, int64_t ld_noise, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                        float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
 {
     if (!h || !action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout: bad argument%s");
     if (ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout: ld_act outside [batch, 2^26]%s");
@@ -567,10 +569,46 @@ int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_
     if (obs_out && !reward_out)
         return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
     const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
+    if (step_noise || reset_noise) {               // nig_rollout_noise: the reference's recorded draws
+        const nig_env_spec &sp = SPECS[h->env];
+        if (h->env > NIG_ENV_ROBOT_ASSEMBLY)
+            return fail(NIG_ERR_UNSUPPORTED, "nig_rollout_noise: only the envs the reference can record draws for (ChemicalReactor, PowerGrid, RobotAssembly)%s");
+        if (out_mode != 3)
+            return fail(NIG_ERR_UNSUPPORTED, "nig_rollout_noise: the injected-draw kernels exist for the row-major trajectory (obs_out with ld_obs == 0) only%s");
+        if (ring_len < n_steps) return fail(NIG_ERR_INVALID, "nig_rollout_noise: recorded draws belong to recorded actions: ring_len >= n_steps%s");
+        if (ld_noise < h->B || ld_noise > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout_noise: ld_noise outside [batch, 2^26]%s");
+        if (sp.k_step > 0 && (!step_noise || step_noise_stride < (int64_t)sp.k_step * ld_noise))
+            return fail(NIG_ERR_INVALID, "nig_rollout_noise: step_noise NULL or its step stride smaller than one [k_step][ld_noise] row set%s");
+        if ((h->flags & NIG_F_AUTORESET) != 0 && sp.k_reset > 0 && (!reset_noise || reset_noise_stride < (int64_t)sp.k_reset * ld_noise))
+            return fail(NIG_ERR_INVALID, "nig_rollout_noise: an auto-reset handle needs reset_noise, step stride >= one [k_reset][ld_noise] row set%s");
+        q.s.step_noise = sp.k_step > 0 ? step_noise : nullptr;
+        q.s.reset_noise = reset_noise;
+        if (!q.s.step_noise && !q.s.reset_noise) q.s.reset_noise = reset_noise ? reset_noise : step_noise;   // (keeps the launcher on the injected-draw path)
+        q.s.ld_noise = (uint32_t)ld_noise;
+        q.nz_step_stride = (uint64_t)step_noise_stride; q.nz_reset_stride = (uint64_t)reset_noise_stride;
+    }
     launch_of(h->env)->rollout(out_mode, q, h->t + 1u, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
     return NIG_OK;
+}
+
+int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
+                int32_t ring_len, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
+{
+    return rollout_impl(h, n_steps, action_ring, ld_act, slot_stride, ring_len, nullptr, 0, nullptr, 0, 0, reward_out, flags_out,
+                        out_stride, obs_out, ld_obs, obs_step_stride, stream);
+}
+
+int nig_rollout_noise(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
+                      int32_t ring_len, const double *step_noise, int64_t step_noise_stride, const double *reset_noise,
+                      int64_t reset_noise_stride, int64_t ld_noise, float *reward_out, uint32_t *flags_out, int64_t out_stride,
+                      float *obs_out, int64_t obs_step_stride, void *stream)
+{
+    if (!step_noise && !reset_noise) return fail(NIG_ERR_INVALID, "nig_rollout_noise: no recorded draws given (use nig_rollout)%s");
+    return rollout_impl(h, n_steps, action_ring, ld_act, slot_stride, ring_len, step_noise, step_noise_stride, reset_noise,
+                        reset_noise_stride, ld_noise, reward_out, flags_out, out_stride, obs_out, 0, obs_step_stride, stream);
 }
 
 int nig_set_policy(nig_handle *h, const nig_policy *policy, void *stream)

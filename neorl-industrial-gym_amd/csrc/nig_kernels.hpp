@@ -608,6 +608,11 @@ struct RolloutArgs {
     float *obs_out; uint32_t ld_obs_out; uint64_t obs_step_stride;   // optional trajectory, [n_steps][S][ld] ...
     int obs_aos;                                                     // ... or row-major transitions [n_steps][B][S]
     uint32_t block0;            // first 256-lane block of this launch (the ragged last block is a launch of its own)
+    // Injected draws (nig_rollout_noise; the NOISE kernel variants): s.step_noise = [n_steps][KS][ld_noise] float64, the
+    // values the reference's np.random calls inside _dynamics returned for call step k (chemical_reactor.py:149,159,
+    // power_grid.py:136-144), s.reset_noise = [n_steps][KR][ld_noise], the draws of _get_initial_state for a lane that
+    // finishes its episode in call step k (base.py:133-155) -- nig_step's parity convention, one row set per step.
+    uint64_t nz_step_stride, nz_reset_stride;   // elements between the row sets of consecutive steps
 };
 
 // OUT: 0 = no per-step outputs, 1 = reward + flag word, 2 = + observation rows [S][ld],
@@ -651,10 +656,15 @@ struct RolloutLds {
 // (PowerGrid: 32 of the registers that capped it at two waves per SIMD).
 // BLK: threads per block (256; 512 for the wide form of envs with a big per-wave LDS scratch: the 12 KiB generator
 // table is then shared by eight waves and two blocks = four waves per SIMD fit a CU).
-template <class Env, int OUT, bool PAIRED, bool FULL, bool NOFREEZE = false, int BLK = 256>
+// NOISE: the reference's recorded draws are injected instead of the generator's (RolloutArgs::nz_*): the step's process
+// noise is loaded as the float64 values the dynamics' parity branch takes, and a finishing lane restarts from
+// Env::init(recorded draws) -- _get_initial_state itself, per lane, in place of the cooperative / compacted schemes
+// (whose work items contain the generator).  Every other instruction of the step is the timed kernel's.
+template <class Env, int OUT, bool PAIRED, bool FULL, bool NOFREEZE = false, int BLK = 256, bool NOISE = false>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
 {
     static_assert(!NOFREEZE || FULL, "NOFREEZE is a property of whole-block launches");
+    static_assert(!NOISE || !PAIRED, "injected draws: nothing to share between the steps of a pair");
     static_assert(BLK == 256 || (Env::COOP_RESET && !Env::COMPACT_RESET), "wide blocks: no block barrier inside the loop");
     constexpr int BLOCK = BLK;                   // shadows the file-wide constant
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
@@ -665,13 +675,13 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     // back from LDS.  Costs two block barriers per step, saves running the whole reset path in
     // every wave for a few active lanes.  ChemicalReactor (0.3 % of lanes per step) keeps the
     // barrier-free divergent form.
-    constexpr bool COMPACT = Env::COMPACT_RESET;
+    constexpr bool COMPACT = Env::COMPACT_RESET && !NOISE;
     // COOP (PowerGrid: ~11 lanes of every wave finish in every step): each WAVE produces the initial states of
     // its own finishing lanes cooperatively -- work item = (finishing lane, generator block) -> a few state rows,
     // spread over all 64 lanes through a wave-private LDS image.  No block barrier (waves keep drifting), the
     // generator runs at ~70 % lane utilisation instead of one wave carrying the whole block's resets while three
     // wait (53 % of the wave cycles of round 1's kernel were spent at those barriers).
-    constexpr bool COOP = Env::COOP_RESET;
+    constexpr bool COOP = Env::COOP_RESET && !NOISE;
     static_assert(!(COMPACT && COOP), "one reset scheme per env");
     constexpr int NWAVE = BLOCK / 64;
     using Lds = RolloutLds<Env, OUT, BLK>;
@@ -730,7 +740,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     // Four steps for the envs whose step is short enough that four copies stay inside the I-cache.
     constexpr int DEPTH = PAIRED ? 4 : 2;
     float buf[DEPTH][A];
-    using nz_t = typename Env::fast_noise_t;
+    using nz_t = std::conditional_t<NOISE, double, typename Env::fast_noise_t>;   // injected draws are fp64
     nz_t nzA[KSN], nzB[KSN];
     nzA[0] = (nz_t)0; nzB[0] = (nz_t)0;
     uint32_t kept0 = 0u, kept1 = 0u;          // words 2-3 of the current pair's block
@@ -759,7 +769,13 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
-        if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
+        if constexpr (NOISE) {
+            if constexpr (KS > 0) {
+                const double *nzr = p.step_noise + (size_t)it * q.nz_step_stride + base;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) nz[k] = in_range ? (nzr + (size_t)k * p.ld_noise)[tid] : 0.0;
+            }
+        } else if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
@@ -825,6 +841,12 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
             // issued above without a wait in between.)
             const unsigned lane = tid & 63u, wave_env0 = base + (tid & ~63u);
             const v4f *tr = s_tr + (tid >> 6) * Lds::TR_STRIDE;
+            // The reads below are OTHER lanes' writes.  The compiler reasons per thread: a lane's own piece 48 l + 16 can
+            // never be the address 16 l + 1024 k it reads, so without this fence it may sink that store out of the loop
+            // (it did, in the injected-draw variant -- the only one whose loop holds no other fence).  Wavefront scope:
+            // pins the compiler's order, emits no wait (the LDS pipeline executes a wave's operations in order).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             v4f *oo = reinterpret_cast<v4f *>(obs_row);
             constexpr int NV = (16 * S + 63) / 64;  // float4 pieces per lane: the wave's block is 64*S floats = 16*S float4
             v4f v[NV];
@@ -881,7 +903,13 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
         } else if constexpr (!COMPACT) {
             if (done && autoreset) {               // divergent per-lane reset (base.py:133-155)
                 double rn[KR > 0 ? KR : 1];
-                Env::draw_init(key, rn);
+                if constexpr (NOISE) {             // _get_initial_state on the recorded draws of this step's row set
+                    const double *rnr = p.reset_noise + (size_t)it * q.nz_reset_stride + base;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) rn[k] = (rnr + (size_t)k * p.ld_noise)[tid];
+                } else {
+                    Env::draw_init(key, rn);
+                }
                 Env::init(rn, n);
                 ctr = 0u;
             }
@@ -969,11 +997,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     }
 }
 
-template <class Env, int OUT, bool PAIRED, bool FULL>
+template <class Env, int OUT, bool PAIRED, bool FULL, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(const RolloutArgs q)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RolloutLds<Env, OUT>::BYTES];
-    rollout_body<Env, OUT, PAIRED, FULL>(q, (blockIdx.x + q.block0) * BLOCK, smem);
+    rollout_body<Env, OUT, PAIRED, FULL, false, 256, NOISE>(q, (blockIdx.x + q.block0) * BLOCK, smem);
 }
 
 // The wide form (envs that declare WIDE_ROLLOUT_BLOCK): whole blocks of BLK lanes of a handle on which no lane can be
@@ -985,28 +1013,28 @@ template <class E> struct wide_rollout<E, std::void_t<decltype(E::WIDE_ROLLOUT_B
 #include "nig_ring.hpp"
 #include "nig_pg_lds.hpp"
 namespace nig {
-template <class Env, int OUT, int BLK>
+template <class Env, int OUT, int BLK, bool NOISE = false>
 struct wide_body {                                // default: the register-resident body without freeze handling
     static constexpr int LDS_BYTES = RolloutLds<Env, OUT, BLK>::BYTES;
     __device__ static __forceinline__ void run(const RolloutArgs &q, uint32_t base, unsigned char *smem)
     {
-        rollout_body<Env, OUT, false, true, true, BLK>(q, base, smem);
+        rollout_body<Env, OUT, false, true, true, BLK, NOISE>(q, base, smem);
     }
 };
-template <int OUT, int BLK>
-struct wide_body<PowerGrid, OUT, BLK> {           // PowerGrid: state staged in LDS (nig_pg_lds.hpp)
+template <int OUT, int BLK, bool NOISE>
+struct wide_body<PowerGrid, OUT, BLK, NOISE> {    // PowerGrid: state staged in LDS (nig_pg_lds.hpp)
     static constexpr int LDS_BYTES = PgLds<BLK>::BYTES;
     __device__ static __forceinline__ void run(const RolloutArgs &q, uint32_t base, unsigned char *smem)
     {
-        pg_lds_rollout_body<OUT, BLK>(q, base, smem);
+        pg_lds_rollout_body<OUT, BLK, false, NOISE>(q, base, smem);
     }
 };
 
-template <class Env, int OUT, int BLK>
+template <class Env, int OUT, int BLK, bool NOISE = false>
 __global__ void __launch_bounds__(BLK, (BLK / 256) * Env::WIDE_ROLLOUT_WAVES) rollout_wide_kernel(const RolloutArgs q)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[wide_body<Env, OUT, BLK>::LDS_BYTES];
-    wide_body<Env, OUT, BLK>::run(q, q.block0 * 256u + blockIdx.x * BLK, smem);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wide_body<Env, OUT, BLK, NOISE>::LDS_BYTES];
+    wide_body<Env, OUT, BLK, NOISE>::run(q, q.block0 * 256u + blockIdx.x * BLK, smem);
 }
 
 }  // namespace nig
@@ -1317,6 +1345,8 @@ __global__ void __launch_bounds__(BLOCK) rollout_policy_kernel(const PolicyArgs 
                     for (int k = 0; k < S; ++k) trf[k] = s[k];
                 }
                 v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)it * q.obs_step_stride + (size_t)(base + (tid & ~63u)) * S);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes' writes are read below: see rollout_body
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 constexpr int NV = (16 * S + 63) / 64;
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
@@ -1731,9 +1761,15 @@ static void launch_step64(const StepArgs &a, bool parity, unsigned grid, hipStre
     }
 }
 
-template <class Env, bool PAIRED, bool FULL>
+// NOISE (here and below): the injected-draw variants of nig_rollout_noise, instantiated for the row-major full-output
+// mode only (out_mode 3, what the headline configuration runs) -- same form selection, same launch shapes.
+template <class Env, bool PAIRED, bool FULL, bool NOISE = false>
 static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
+    if constexpr (NOISE) {
+        hipLaunchKernelGGL((rollout_kernel<Env, 3, false, FULL, true>), dim3(grid), dim3(BLOCK), 0, st, q);
+        return;
+    }
     switch (out_mode) {
     case 0: hipLaunchKernelGGL((rollout_kernel<Env, 0, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
     case 1: hipLaunchKernelGGL((rollout_kernel<Env, 1, PAIRED, FULL>), dim3(grid), dim3(BLOCK), 0, st, q); break;
@@ -1743,12 +1779,12 @@ static void launch_rollout_blocks(int out_mode, const RolloutArgs &q, unsigned g
 }
 
 // the batch's whole 256-lane blocks in one launch without lane predication, a ragged last block in its own
-template <class Env, bool PAIRED>
+template <class Env, bool PAIRED, bool NOISE = false>
 static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*grid*/, hipStream_t st)
 {
     const unsigned n_full = q.s.B / BLOCK;
     RolloutArgs r = q;
-    if constexpr ((PAIRED || Env::KS == 0) && split_rollout<Env>::value) {
+    if constexpr ((PAIRED || Env::KS == 0 || NOISE) && split_rollout<Env>::value) {
         // Up to one 256-lane block per CU the batch leaves a single wave on every SIMD: producer / integrator /
         // recorder wave per 64 lanes instead (nig_split.hpp; one block per CU is resident).  Larger batches run that
         // form in ROUNDS of one block per CU, which beats the one-wave form (lanes filling the SIMDs) by 4-12 % when
@@ -1761,8 +1797,8 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
                                                     (split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
         if (plain && n_full > 0 && even_rounds) {
             r.block0 = 0;
-            launch_split_blocks<Env, BLOCK / 64>(out_mode, r, n_full, st);
-            if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
+            launch_split_blocks<Env, BLOCK / 64, NOISE>(out_mode, r, n_full, st);
+            if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false, NOISE>(out_mode, r, 1u, st); }
             return;
         }
     }
@@ -1781,6 +1817,8 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
             const unsigned n_wide = q.s.B / WB;
             if (n_wide > 0 && n_wide >= q.s.wide_min_blocks) {
                 r.block0 = 0;
+                if constexpr (NOISE) hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, WB, true>), dim3(n_wide), dim3(WB), 0, st, r);
+                else
                 switch (out_mode) {
                 case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
                 case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, WB>), dim3(n_wide), dim3(WB), 0, st, r); break;
@@ -1795,6 +1833,8 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
                 // stepping wave (rollout_pg_pair_kernel, nig_pg_lds.hpp)
                 if (first == 0 && n_full > 0 && q.s.split_blocks != 0 && n_full <= q.s.split_blocks) {
                     r.block0 = 0;
+                    if constexpr (NOISE) hipLaunchKernelGGL((rollout_pg_pair_kernel<3, true>), dim3(n_full), dim3(512), 0, st, r);
+                    else
                     switch (out_mode) {
                     case 0: hipLaunchKernelGGL((rollout_pg_pair_kernel<0>), dim3(n_full), dim3(512), 0, st, r); break;
                     case 1: hipLaunchKernelGGL((rollout_pg_pair_kernel<1>), dim3(n_full), dim3(512), 0, st, r); break;
@@ -1807,6 +1847,8 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
             if (n_full > first) {
                 r.block0 = first;
                 const unsigned nb = n_full - first;
+                if constexpr (NOISE) hipLaunchKernelGGL((rollout_wide_kernel<Env, 3, BLOCK, true>), dim3(nb), dim3(BLOCK), 0, st, r);
+                else
                 switch (out_mode) {
                 case 0: hipLaunchKernelGGL((rollout_wide_kernel<Env, 0, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
                 case 1: hipLaunchKernelGGL((rollout_wide_kernel<Env, 1, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, r); break;
@@ -1817,14 +1859,21 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
             }
         }
     }
-    if (n_full > first) { r.block0 = first; launch_rollout_blocks<Env, PAIRED, true>(out_mode, r, n_full - first, st); }
-    if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false>(out_mode, r, 1u, st); }
+    if (n_full > first) { r.block0 = first; launch_rollout_blocks<Env, PAIRED, true, NOISE>(out_mode, r, n_full - first, st); }
+    if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false, NOISE>(out_mode, r, 1u, st); }
 }
 
 // t0 = launch counter of the call's first step (host-known: rollouts are never graph-captured)
+// the envs the reference can record draws for (ChemicalReactor, PowerGrid, RobotAssembly): nig_rollout_noise
+template <class Env> struct noise_rollout : std::bool_constant<(Env::ID <= 2)> {};
+
 template <class Env>
 static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, unsigned grid, hipStream_t st)
 {
+    if (q.s.step_noise != nullptr || q.s.reset_noise != nullptr) {       // injected draws (nig_rollout_noise has validated the request)
+        if constexpr (noise_rollout<Env>::value) launch_rollout_form<Env, false, true>(3, q, grid, st);
+        return;
+    }
     if constexpr (Env::SHARED_STEP_BLOCK) {
         RolloutArgs r = q;
         if ((t0 & 1u) == 0u) {                    // starts on the second step of a pair: peel it

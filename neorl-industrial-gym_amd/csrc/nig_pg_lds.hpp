@@ -48,19 +48,24 @@ struct PgLds {
 // reward + flags (profiles/r03/pg_pair_ab.txt); the stepping wave is what bounds it then (a chain of LDS round trips
 // through its state image: ~10 cycles per instruction) -- TWO producers per stepping wave, three generator blocks each,
 // were no faster (711 / 676 us).
-struct PgPairLds {
+// NOISE (nig_rollout_noise: the reference's recorded float64 draws instead of the generator's): a slot holds the step's 23
+// draws as doubles, [draw][lane], because power_grid.py:136-144 adds them in float64.
+template <bool NOISE>
+struct PgPairLdsT {
     static constexpr int K = 2;                                   // ring slots (steps) per pair
-    static constexpr int SLOT_V4 = 6 * 64;                        // float4 per slot: [generator block][lane]
+    static constexpr int SLOT_V4 = NOISE ? 23 * 64 / 2 : 6 * 64;  // float4 per slot: [generator block][lane] (NOISE: 23 x 64 doubles)
     static constexpr int OFF_NZ = (PgLds<256>::BYTES + 15) / 16 * 16;
     static constexpr int OFF_SYNC = OFF_NZ + 4 * K * SLOT_V4 * 16;     // uint32 [4 pairs][4]: {produced, consumed}
     static constexpr int BYTES = OFF_SYNC + 4 * 16;
     static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
+using PgPairLds = PgPairLdsT<false>;
 
 // producer wave `wave` (0-3) of the block: lanes base + 64 wave .. + 63, local steps [0, n)
+template <bool NOISE = false>
 __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uint32_t base, unsigned char *smem, const unsigned wave, const unsigned lane)
 {
-    using L = PgPairLds;
+    using L = PgPairLdsT<NOISE>;
     const float4 *const s_probit = reinterpret_cast<const float4 *>(smem + PgLds<256>::OFF_PROBIT);
     v4f *const ring = reinterpret_cast<v4f *>(smem + L::OFF_NZ) + wave * (L::K * L::SLOT_V4);
     lds_u32_t *const sync = (lds_u32_t *)(smem + L::OFF_SYNC) + wave * 4;
@@ -69,6 +74,21 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
     const uint64_t gi = p.env0 + (uint64_t)(base + wave * 64u + lane);
     const int n = q.n_steps - q.it0;
     uint32_t freed = 0u;                                           // slots the stepping wave is known to be done with
+    if constexpr (NOISE) {                         // the step's recorded draws, loaded where the generator would have produced them
+        double *const ringd = reinterpret_cast<double *>(ring);
+        for (int i = 0; i < n; ++i) {
+            const double *nzr = p.step_noise + (size_t)(q.it0 + i) * q.nz_step_stride + base + wave * 64u;
+            double z[23];
+#pragma unroll
+            for (int k = 0; k < 23; ++k) z[k] = (nzr + (size_t)k * p.ld_noise)[lane];
+            if (freed + (uint32_t)L::K < (uint32_t)i + 1u) freed = split_wait(sync + 1, (uint32_t)(i + 1 - L::K));
+            double *slot = ringd + (i & (L::K - 1)) * (L::SLOT_V4 * 2);
+#pragma unroll
+            for (int k = 0; k < 23; ++k) slot[64 * k + lane] = z[k];
+            split_post(sync + 0, (uint32_t)i + 1u, lane);
+        }
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         const RngKey key = make_key(gi, t_base + (uint32_t)i + 1u, p.seed_lo, p.seed_hi, s_probit);
         v4f z[6];
@@ -88,12 +108,16 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
     }
 }
 
-template <int OUT, int BLK, bool PROD = false>
+// NOISE: nig_rollout_noise -- the step's 23 draws are the reference's recorded float64 values (loaded from the caller's
+// rows, or read from the producer's slot in the paired form) and enter through the float64 adds of power_grid.py:136-144
+// (PowerGrid::dynamics' parity branch); a finishing lane's image row is rewritten with PowerGrid::init(recorded draws).
+template <int OUT, int BLK, bool PROD = false, bool NOISE = false>
 __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
 {
     using Env = PowerGrid;
     constexpr int S = Env::S, A = Env::A;
     using Lds = PgLds<BLK>;
+    using PgPairLds = PgPairLdsT<NOISE>;
     static_assert(!PROD || BLK == 256, "the paired form runs 256-lane blocks");
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
     if constexpr (!PROD) {                         // (paired form: the kernel staged the table with all its waves)
@@ -202,7 +226,20 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             [[maybe_unused]] const int itl = it - q.it0;                 // local step: the producer's slot index
             [[maybe_unused]] const v4f *const nzs = nz_ring + (itl & (PgPairLds::K - 1)) * PgPairLds::SLOT_V4;
             u32x4 x = {0u, 0u, 0u, 0u};
-            if constexpr (PROD) {
+            // NOISE: draw k of this step, float64 -- from the producer's slot (paired form) or the caller's rows
+            [[maybe_unused]] const double *const nzd_lds = reinterpret_cast<const double *>(nzs) + lane;
+            [[maybe_unused]] const double *const nzd_glb = NOISE ? p.step_noise + (size_t)it * q.nz_step_stride + base + tid : nullptr;
+            [[maybe_unused]] auto nzd = [&](int k) __attribute__((always_inline)) -> double {
+                if constexpr (PROD) return nzd_lds[64 * k];
+                else return (nzd_glb + (size_t)k * p.ld_noise)[0];
+            };
+            if constexpr (NOISE) {
+                if constexpr (PROD) {
+                    if (nz_seen < (uint32_t)itl + 1u) nz_seen = split_wait(nz_sync + 0, (uint32_t)itl + 1u);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (float)((double)v[k] + nzd(k));      // :136-137 fp64 add, one rounding
+            } else if constexpr (PROD) {
                 if (nz_seen < (uint32_t)itl + 1u) nz_seen = split_wait(nz_sync + 0, (uint32_t)itl + 1u);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -260,7 +297,15 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             for (int j = 2; j < 6; ++j) {
                 ProbitFetch f[4];
                 v4f zq = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (PROD) {
+                [[maybe_unused]] double zd[4] = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (NOISE) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * j + c < 23) zd[c] = nzd(4 * j + c);
+                    if constexpr (PROD) {
+                        if (j == 5) split_post(nz_sync + 1, (uint32_t)itl + 1u, lane);
+                    }
+                } else if constexpr (PROD) {
                     zq = nzs[64 * j + lane];
                     if (j == 5) split_post(nz_sync + 1, (uint32_t)itl + 1u, lane);     // (DS order: the reads above execute before this write)
                 } else {
@@ -273,13 +318,20 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     if constexpr (PROD) return c == 0 ? zq.x : c == 1 ? zq.y : c == 2 ? zq.z : zq.w;
                     else return probit_eval(f[c]);
                 };
+                // one random-walk update: load rows (:140-141, clipped at 0) and line-flow rows (:144, sd 2.0)
+                auto walk_load = [&](float h, int c) __attribute__((always_inline)) -> float {
+                    if constexpr (NOISE) { double l = (double)h + zd[c]; l = (l < 0.0) ? 0.0 : l; return (float)l; }
+                    else { const float l = h + zn(c); return (l < 0.0f) ? 0.0f : l; }
+                };
+                auto walk_flow = [&](float h, int c) __attribute__((always_inline)) -> float {
+                    if constexpr (NOISE) return (float)((double)h + zd[c]);
+                    else return h + 2.0f * zn(c);
+                };
                 asm volatile("" ::: "memory");                               // the groups are read again HERE, not kept from the top
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == 2) {                      // load[0..3]: group 4 = {gen7, load0, load1, load2}, load3 = group 5 .x
                     const v4f h4 = mine[32], h5 = mine[40];
-                    float l[4] = {h4.y + zn(0), h4.z + zn(1), h4.w + zn(2), h5.x + zn(3)};   // :140
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];                                   // :141
+                    float l[4] = {walk_load(h4.y, 0), walk_load(h4.z, 1), walk_load(h4.w, 2), walk_load(h5.x, 3)};   // :140-141
                     v4f w4 = {ngen7, l[0], l[1], l[2]};
                     mine[32] = w4;
                     l7 = l[3];                     // load3', parked until its group is complete
@@ -289,9 +341,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     }
                 } else if (j == 3) {               // load[4..7]: group 5 = {load3 .. load6}, load7 = group 6 .x
                     const v4f h5 = mine[40], h6 = mine[48];
-                    float l[4] = {h5.y + zn(0), h5.z + zn(1), h5.w + zn(2), h6.x + zn(3)};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) l[c] = (l[c] < 0.0f) ? 0.0f : l[c];
+                    float l[4] = {walk_load(h5.y, 0), walk_load(h5.z, 1), walk_load(h5.w, 2), walk_load(h6.x, 3)};
                     v4f w5 = {l7, l[0], l[1], l[2]};
                     mine[40] = w5;
                     if constexpr (OUT == 2) {
@@ -302,8 +352,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     l7 = l[3];                     // load7'
                 } else if (j == 4) {               // flows[0..3]: group 6 = {load7, flow0, flow1, flow2}, flow3 = group 7 .x
                     const v4f h6 = mine[48], h7 = mine[56];
-                    const float fl[4] = {h6.y + 2.0f * zn(0), h6.z + 2.0f * zn(1),
-                                         h6.w + 2.0f * zn(2), h7.x + 2.0f * zn(3)};          // :144
+                    const float fl[4] = {walk_flow(h6.y, 0), walk_flow(h6.z, 1), walk_flow(h6.w, 2), walk_flow(h7.x, 3)};   // :144
                     v4f w6 = {l7, fl[0], fl[1], fl[2]};
                     mine[48] = w6;
                     if constexpr (OUT == 2) {
@@ -314,7 +363,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                     l7 = fl[3];                    // flow3'
                 } else {                           // flows[4..6]: group 7 = {flow3 .. flow6}
                     const v4f h7 = mine[56];
-                    const float fl[3] = {h7.y + 2.0f * zn(0), h7.z + 2.0f * zn(1), h7.w + 2.0f * zn(2)};
+                    const float fl[3] = {walk_flow(h7.y, 0), walk_flow(h7.z, 1), walk_flow(h7.w, 2)};
                     v4f w7 = {l7, fl[0], fl[1], fl[2]};
                     mine[56] = w7;
                     if constexpr (OUT == 2) {
@@ -329,6 +378,8 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                 // the image now holds the wave's 64 post-step rows: row-major float4 64 j + lane sits at 64 j + rd
                 v4f *oo = reinterpret_cast<v4f *>(obs_row);
                 v4f v[8];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes' writes are read below (compiler order only: rollout_body)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef NIG_DIAG_PG_NOLDSREAD           // (diagnostic builds only, profiles/r03/pg_store_probe2.sh: what do the transposed reads cost?)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { v4f w = {ngen7, l7, (float)j, ngen7}; v[j] = w; }
@@ -350,7 +401,20 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             if constexpr (OUT >= 2) obs_row += q.obs_step_stride;
             // ---- IndustrialEnv.reset for the lanes that finished (base.py:133-155), wave-cooperative: work item =
             // (finishing lane, generator block) -> four state values, written into that lane's image row
-            const unsigned long long m = __ballot(done);
+            if constexpr (NOISE) {
+                if (done) {                        // _get_initial_state on the recorded draws of this step's row set, into the lane's own image row
+                    double rn[Env::KR];
+                    const double *rnr = p.reset_noise + (size_t)it * q.nz_reset_stride + base + tid;
+#pragma unroll
+                    for (int k = 0; k < Env::KR; ++k) rn[k] = (rnr + (size_t)k * p.ld_noise)[0];
+                    float r0[S];
+                    Env::init(rn, r0);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) { v4f w = {r0[4 * g], r0[4 * g + 1], r0[4 * g + 2], r0[4 * g + 3]}; mine[8 * g] = w; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            const unsigned long long m = NOISE ? 0ull : __ballot(done);
             if (m != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
                 if (done) wl[rank] = (unsigned char)lane;
@@ -402,18 +466,19 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
 
 // The paired form's kernel: 256 lanes per block, 512 threads -- waves 0-3 step (pg_lds_rollout_body, PROD), waves 4-7
 // produce their normals (pg_pair_producer).  q.block0 counts 256-lane blocks.  One block per compute unit is resident.
-template <int OUT>
+template <int OUT, bool NOISE = false>
 __global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutArgs q)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PgPairLds::BYTES];
+    using PL = PgPairLdsT<NOISE>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PL::BYTES];
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + PgLds<256>::OFF_PROBIT);
     for (int i_ = (int)threadIdx.x; i_ < 768; i_ += 512) s_probit[i_] = NIG_PROBIT[i_];
-    if (threadIdx.x < 16u) reinterpret_cast<uint32_t *>(smem + PgPairLds::OFF_SYNC)[threadIdx.x] = 0u;
+    if (threadIdx.x < 16u) reinterpret_cast<uint32_t *>(smem + PL::OFF_SYNC)[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t base = (blockIdx.x + q.block0) * 256u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= 4u) pg_pair_producer(q, base, smem, wave - 4u, threadIdx.x & 63u);
-    else pg_lds_rollout_body<OUT, 256, true>(q, base, smem);
+    if (wave >= 4u) pg_pair_producer<NOISE>(q, base, smem, wave - 4u, threadIdx.x & 63u);
+    else pg_lds_rollout_body<OUT, 256, true, NOISE>(q, base, smem);
 }
 
 template <class E, class = void> struct pair_rollout : std::false_type {};

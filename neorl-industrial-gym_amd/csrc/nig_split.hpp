@@ -62,7 +62,12 @@ struct SplitLds {
 // wave 2 NP + w their recorder (a block's waves go to the CU's four SIMDs round-robin: with NP = 4 the three
 // share one).  Whole 64*NP-lane blocks only, auto-reset handles without frozen lanes only, and for an env with step
 // noise a launch starting on an odd counter (PAIRED form): the host keeps every other case on rollout_kernel.
-template <class Env, int OUT, int NP>
+// NOISE (nig_rollout_noise): the reference's recorded draws instead of the generator's -- the producer LOADS the step's
+// process noise (float64 rows, handed on as the float the fast-mode ring carries: ChemicalReactor's dynamics round the
+// draw to float32 before they use it, chemical_reactor.py:149,159 under NEP 50, so nothing is lost) and a finishing lane
+// restarts from Env::init(recorded draws), per lane, in place of the cooperative reset.  Ring protocol, roles, clip,
+// constraint check, dynamics, reward, flags, tally and stores are the timed kernel's, instruction for instruction.
+template <class Env, int OUT, int NP, bool NOISE = false>
 __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const RolloutArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS;
@@ -137,10 +142,20 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             reinterpret_cast<uint32_t *>(ih + S * 64)[lane] = vb;
             split_post(sync + 1, (uint32_t)i + 1u, lane);
             step = done ? 0 : step + 1;
+            if constexpr (NOISE) {
+                if (done) {                        // IndustrialEnv.reset on the recorded draws of this step's row set (base.py:133-155)
+                    double rn[Env::KR > 0 ? Env::KR : 1];
+                    const double *rnr = p.reset_noise + (size_t)(q.it0 + i) * q.nz_reset_stride + base;
+#pragma unroll
+                    for (int k = 0; k < Env::KR; ++k) rn[k] = (rnr + (size_t)k * p.ld_noise)[lane];
+                    Env::init(rn, nx);
+                }
+            } else {
             const unsigned long long m = __ballot(done);
             if (m != 0ull)
                 coop_reset<Env>(m, done, lane, s_img, s_wlist, p.env0 + (uint64_t)base, t_base + (uint32_t)i + 1u,
                                 p.seed_lo, p.seed_hi, s_probit, nx);
+            }
 #pragma unroll
             for (int k = 0; k < S; ++k) s[k] = nx[k];
             if (i + 1 < n && __builtin_amdgcn_readfirstlane(c_next) < (uint32_t)i + 2u) {   // rare: the producer fell behind
@@ -185,7 +200,11 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             constexpr int r = decltype(r_tag)::value;
             float (&ab)[A] = buf[r];
             typename Env::fast_noise_t nz[KN];
-            if constexpr (KS > 0) {
+            if constexpr (KS > 0 && NOISE) {
+                const double *nzr = p.step_noise + (size_t)(q.it0 + j) * q.nz_step_stride + base;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) nz[k] = (nzr + (size_t)k * p.ld_noise)[lane];
+            } else if constexpr (KS > 0) {
                 ProbitFetch pf[KN];
                 if constexpr ((r & 1) == 0) {     // first step of a pair: the pair's Philox block
                     const u32x4 x = Env::step_block(make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit));
@@ -317,9 +336,13 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
 }
 
 // whole blocks of 64*NP lanes, PAIRED start; the caller (launch_rollout_form) has checked that the form applies
-template <class Env, int NP>
+template <class Env, int NP, bool NOISE = false>
 static void launch_split_blocks(int out_mode, const RolloutArgs &q, unsigned grid, hipStream_t st)
 {
+    if constexpr (NOISE) {                         // injected draws: the row-major full-output variant only (nig_rollout_noise)
+        hipLaunchKernelGGL((split_rollout_kernel<Env, 3, NP, true>), dim3(grid), dim3(192 * NP), 0, st, q);
+        return;
+    }
     switch (out_mode) {
     case 0: hipLaunchKernelGGL((split_rollout_kernel<Env, 0, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;
     case 1: hipLaunchKernelGGL((split_rollout_kernel<Env, 1, NP>), dim3(grid), dim3(192 * NP), 0, st, q); break;

@@ -63,9 +63,10 @@ def test_tune_knob_needs_no_gpu():
     before = L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS)
     assert before >= 0 and L.nig_tune_get(99) == -1
     assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, 12) == 0 and L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == 12
-    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, -1) != 0 and L.nig_tune(99, 1) != 0
+    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, -2) != 0 and L.nig_tune(99, 1) != 0
     assert L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == 12
-    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, before) == 0
+    # -1 = no explicit setting: back to the per-device default
+    assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, -1) == 0 and L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == before
 
 
 def test_layout_query():

@@ -270,5 +270,5 @@ def test_tune_knob_roundtrip(ni):
     assert ni.tune(split_blocks=17)["split_blocks"] == 17
     assert ni.tune()["split_blocks"] == 17
     with pytest.raises(Exception):
-        ni.tune(split_blocks=-1)
+        ni.tune(split_blocks=-2)
     assert ni.tune(split_blocks=256)["split_blocks"] == 256
