@@ -15,8 +15,8 @@ import sys
 from collections import defaultdict
 
 
-ROLLOUT_RX = r"rollout_kernel|rollout_wide_kernel|split_rollout_kernel"     # the fused-rollout kernel forms
-ROUND = os.environ.get("NIG_PROFILE_ROUND", "r03")                           # directory under profiles/ the record is kept in
+ROLLOUT_RX = r"rollout_kernel|rollout_wide_kernel|split_rollout_kernel|rollout_pg_pair_kernel|mixed_rollout_kernel"     # the fused-rollout kernel forms
+ROUND = os.environ.get("NIG_PROFILE_ROUND", "r04")                           # directory under profiles/ the record is kept in
 
 
 def load(path):
@@ -30,15 +30,16 @@ def main():
     out, tag = sys.argv[1], sys.argv[2]
     args = sys.argv[3:]
     env = args[args.index("--env") + 1] if "--env" in args else "cr"
-    S = {"cr": 12, "pg": 32, "ra": 24}[env]
-    B = int(args[args.index("--batch") + 1]) if "--batch" in args else {"cr": 65536, "pg": 262144, "ra": 262144}[env]
+    S = {"cr": 12, "pg": 32, "ra": 24, "mixed": 12}[env]
+    B = int(args[args.index("--batch") + 1]) if "--batch" in args else {"cr": 65536, "pg": 262144, "ra": 262144, "mixed": 1048576}[env]
+    calB = 65536 if env == "mixed" else B           # bench_mixed calibrates on a 65 536-lane ChemicalReactor handle
     P = int(args[args.index("--plan-steps") + 1]) if "--plan-steps" in args else 250
     mode = args[args.index("--mode") + 1] if "--mode" in args else "rollout"
     res = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         per = load(os.path.join(out, f"{tag}_{ctr}.csv"))
         cal = [v for k, vs in per.items() if "copy_rows_kernel" in k for v in vs]
-        known = S * B * 4.0                       # bytes read (and written) by one copy_rows dispatch
+        known = S * calB * 4.0                    # bytes read (and written) by one copy_rows dispatch
         cal = sorted(cal)[len(cal) // 2] if cal else None
         scale = (known / cal) if cal else None    # bytes per counter unit for dword-per-lane rows
         for k, vs in per.items():
@@ -62,6 +63,8 @@ def main():
     print(json.dumps(summary, indent=1))
     # merge into profiles/traffic.json under the key bench.py looks up: <env>_<B>_<mode>_<outputs|step>
     outputs = args[args.index("--outputs") + 1] if "--outputs" in args else "full"
+    if env == "mixed":
+        outputs = args[args.index("--mixed-outputs") + 1] if "--mixed-outputs" in args else "full"
     want = ROLLOUT_RX if mode == "rollout" else "step_kernel"
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     try:

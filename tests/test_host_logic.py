@@ -2,6 +2,7 @@
 exchange, the 13-key aggregation against the reference's golden evaluate_with_safety dicts,
 and the boundary types."""
 import os
+import time
 import sys
 
 import numpy as np
@@ -344,6 +345,51 @@ def test_bench_launches_and_verifies_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["tally_check"]["ranks"] == 2
     assert rec["episodes_per_rank"] == [100, 101] and rec["tally"]["episodes"] == 201
     assert rec["value"] is None and "rehearsal" in rec          # never mistaken for a measurement
+    # the N-rank line says what it is: a rehearsal, not a hardware curve; every rank's own time; where the ranks were pinned
+    assert rec["scale"]["measured_on_hardware"] is False and rec["scale"]["world"] == 2 and "REHEARSAL" in rec["scale"]["note"]
+    rt = rec["rank_times"]
+    assert rt["ranks"] == 2 and len(rt["wall_s_per_rank"]) == 2 and len(rt["launch_us_per_rank"]) == 2
+    assert rt["wall_min_s"] <= rt["wall_median_s"] <= rt["wall_max_s"] == max(rt["wall_s_per_rank"])
+    assert rec["ms_per_step"] == pytest.approx(rt["wall_max_s"] * 1e3 / 3)         # the line's time IS the slowest rank's interval
+    aff = rec["scale"]["rank_affinity"]
+    assert len(aff) == 2 and all("pinned" in a for a in aff)
+    if all(a["pinned"] for a in aff):                                               # disjoint CPU shares
+        assert aff[0]["last_cpu"] < aff[1]["first_cpu"] or aff[1]["last_cpu"] < aff[0]["first_cpu"]
+    # N = 1 and N = 2 time the same set of operations: K launches + the stream synchronisation, no collective inside
+    p1, rec1 = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1"], {"NIG_BENCH_REHEARSE": "cpu"})
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    assert rec1["rank_times"]["timed_interval"] == rt["timed_interval"] and "outside the interval" in rt["timed_interval"]
+    assert rec1["scale"]["measured_on_hardware"] is False and rec1["scale"]["world"] == 1
+
+
+def test_bench_timed_interval_holds_no_collective():
+    """bench.timed(): the clock stops after the stream synchronisation and BEFORE the closing barrier (VERDICT r03 weak #5:
+    with world > 1 the wall clock used to include one dist.barrier() the N = 1 run never pays)."""
+    import bench
+    import torch
+    calls = []
+
+    class FakeDist:
+        def barrier(self):
+            calls.append(("barrier", time.perf_counter()))
+            time.sleep(0.05)
+
+        def all_gather(self, out, t):
+            for o in out:
+                o.copy_(t)
+
+    class W:
+        def launch(self):
+            calls.append(("launch", time.perf_counter()))
+
+        def kernels_per_launch(self):
+            return 1
+    stats = {}
+    wall, _ = bench.timed(torch, FakeDist(), 2, torch.device("cpu"), W(), 4, 1, stats=stats)
+    kinds = [k for k, _ in calls]
+    assert kinds == ["launch", "barrier", "launch", "launch", "launch", "launch", "barrier"]
+    assert wall < 0.04, wall                     # neither 50 ms barrier is inside the interval
+    assert stats["wall_s_per_rank"] == [wall, wall]
 
 
 def test_bench_does_not_spawn_under_a_profiler_preload():
