@@ -125,6 +125,9 @@ typedef struct nig_layout {
 
 typedef struct nig_handle nig_handle;
 
+/* "nig <major.minor.patch> (gfx950; generator <id>)".  The generator id names the fast-mode random stream: trajectories of a
+ * given (seed, lane, launch counter) are reproducible only under the same id ("nig-philox-v1" up to 0.1.0; "nig-philox-v2":
+ * Philox4x32-7, float32 reset draws, since 0.2.0). */
 const char *nig_version(void);
 const char *nig_last_error(void);
 
@@ -149,7 +152,12 @@ const char *nig_last_error(void);
  * A value of -1 removes an explicit setting: every handle is back on its own device's default (tests restore with it).
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / value below -1); nig_tune_get returns the value in effect
  * for the device of the latest handle, or -1 for an unknown key. */
-enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1 };
+/* NIG_TUNE_DIAG_RING_FAULT: exists in the TEST-ONLY library variant built with -DNIG_RING_SPIN_LIMIT=<polls>
+ * (profiles/mkvariant.sh; csrc/nig_ring.hpp) -- there the cooperating-wave kernels' ring waits are bounded and a
+ * time-out makes nig_rollout / nig_rollout_policy return NIG_ERR_HIP naming the ring (they synchronise the stream in that
+ * build); a non-zero value makes the producing waves stop posting after 7 steps, which is how tests/test_gpu_ring_limit.py
+ * shows the error path.  The production library returns NIG_ERR_UNSUPPORTED for this key. */
+enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1, NIG_TUNE_DIAG_RING_FAULT = 2 };
 int nig_tune(int32_t key, int64_t value);
 int64_t nig_tune_get(int32_t key);
 

@@ -37,7 +37,8 @@ def tune(split_blocks=None, wide_min_blocks=None):
             "wide_min_blocks": int(L.nig_tune_get(_lib.TUNE_WIDE_MIN_BLOCKS))}
 
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"        # generator "nig-philox-v2" since round 3 (libnig: nig_version())
+GENERATOR = "nig-philox-v2"
 __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
     "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "AdvancedChemicalReactorEnv", "AdvancedPowerGridEnv",

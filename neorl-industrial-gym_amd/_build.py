@@ -108,6 +108,52 @@ def build(force=False, verbose=False, jobs=None):
     return LIB
 
 
+# Test-only library variants (loaded through NIG_LIB_PATH, never as libnig.so): name -> (translation units recompiled, flags)
+VARIANTS = {
+    # bounded ring waits + error reporting (csrc/nig_ring.hpp; tests/test_gpu_ring_limit.py)
+    "ringlimit": (["env_cr", "env_pg", "env_ra", "nig_api"], ["-DNIG_RING_SPIN_LIMIT=4000000"]),
+}
+
+
+def variant_path(name):
+    return os.path.join(_HERE, f"libnig_{name}.so")
+
+
+def build_variant(name, verbose=False):
+    """libnig_<name>.so = libnig.so's objects with the variant's translation units recompiled with its flags.
+    Current when its stamp equals the hash of the sources + flags."""
+    tus, flags = VARIANTS[name]
+    out = variant_path(name)
+    stamp = out + ".srchash"
+    want = source_hash() + " " + " ".join(flags)
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
+    build(verbose=verbose)
+    hipcc = find_hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build a library variant")
+    vdir = os.path.join(OBJ, "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+
+    def one(tu):
+        obj = os.path.join(vdir, tu + ".o")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-w"] + flags + ["-c", "-o", obj, os.path.join(CSRC, tu + ".hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=max(1, min(len(tus), os.cpu_count() or 2))) as ex:
+        vobjs = list(ex.map(one, tus))
+    base = [os.path.join(OBJ, os.path.splitext(os.path.basename(s_))[0] + ".o") for s_ in sources()
+            if os.path.splitext(os.path.basename(s_))[0] not in tus]
+    tmp = f"{out}.tmp.{os.getpid()}"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + base + vobjs + ["-ldl"])
+    os.replace(tmp, out)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return out
+
+
 def ensure(verbose=False):
     """What importing the package calls.  Never compiles inside a profiled or GPU-initialised
     process: with NIG_NO_AUTOBUILD set, or under a rocprofiler preload, a stale library is an error

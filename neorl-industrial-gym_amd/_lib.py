@@ -27,6 +27,7 @@ MAX_EPISODE_STEPS = 21845
 
 TUNE_SPLIT_BLOCKS = 0
 TUNE_WIDE_MIN_BLOCKS = 1
+TUNE_DIAG_RING_FAULT = 2
 
 SYMBOLS = [
     "nig_version", "nig_last_error", "nig_env_id", "nig_env_name", "nig_env_spec_get", "nig_layout_query",

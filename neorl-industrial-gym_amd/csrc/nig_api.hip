@@ -220,6 +220,8 @@ static const EnvLaunch *launch_of(int env)
 static int enabled_constraints(const nig_handle *h);
 namespace nig { unsigned split_blocks_for(unsigned cus); unsigned wide_min_blocks_for(unsigned cus); }
 
+namespace nig { static std::atomic<unsigned> g_diag_ring_fault{0u}; }   // NIG_RING_SPIN_LIMIT builds: nig_tune(NIG_TUNE_DIAG_RING_FAULT)
+
 static StepArgs base_step_args(const nig_handle *h)
 {
     const nig_layout &L = h->lay;
@@ -235,7 +237,33 @@ static StepArgs base_step_args(const nig_handle *h)
     a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.cmask = h->cmask;
     a.hflags = h->flags | (h->may_hold_done ? HF_MAY_HOLD_DONE : 0u);
     a.n_en = enabled_constraints(h);
+#ifdef NIG_RING_SPIN_LIMIT
+    a.ring_err = h->t_dev + 16;                    // a spare word of the 256-byte launch-counter slot (zeroed at nig_create)
+    if (nig::g_diag_ring_fault.load(std::memory_order_relaxed)) a.hflags |= HF_DIAG_RING_FAULT;
+#endif
     return a;
+}
+
+// NIG_RING_SPIN_LIMIT builds (test-only, nig_ring.hpp): after a launch of a cooperating-wave kernel, wait for it and turn a
+// recorded ring time-out into NIG_ERR_HIP.  The production build returns at once: no hidden synchronisation there.
+static int ring_check(nig_handle *h, hipStream_t st, const char *who)
+{
+#ifdef NIG_RING_SPIN_LIMIT
+    uint32_t code = 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(&code, h->t_dev + 16, 4, hipMemcpyDeviceToHost));
+    if (code != 0u) {
+        HIP_TRY(hipMemset(h->t_dev + 16, 0, 4));
+        static const char *const ring[3] = {"inputs (producer -> stepper)", "results (stepper -> recorder)", "slots released (consumer -> producer)"};
+        char detail[256];
+        snprintf(detail, sizeof detail, "%s: a wave waited more than %d polls for count %u of ring counter %u, '%s'; every role left its loop, "
+                 "results of this launch are invalid", who, (int)(NIG_RING_SPIN_LIMIT), (code >> 16) & 0x7FFFu, code & 3u, ring[(code & 3u) % 3]);
+        return fail(NIG_ERR_HIP, "ring protocol time-out -- %s", detail);
+    }
+#else
+    (void)h; (void)st; (void)who;
+#endif
+    return NIG_OK;
 }
 
 static int enabled_constraints(const nig_handle *h)
@@ -277,11 +305,21 @@ unsigned wide_min_blocks_for(unsigned cus)
 
 extern "C" {
 
-const char *nig_version(void) { return "nig 0.1.0 (gfx950)"; }
+// 0.2.0: the fast-mode generator is "nig-philox-v2" (Philox4x32-7, float32 reset draws for ChemicalReactor / PowerGrid, round 3):
+// every (seed, lane, t) trajectory differs from 0.1.0's "nig-philox-v1" -- stored seeds / datasets are tied to the generator id
+const char *nig_version(void) { return "nig 0.2.0 (gfx950; generator nig-philox-v2)"; }
 const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)
 {
+    if (key == NIG_TUNE_DIAG_RING_FAULT) {
+#ifdef NIG_RING_SPIN_LIMIT
+        nig::g_diag_ring_fault.store(value != 0 ? 1u : 0u, std::memory_order_relaxed);
+        return NIG_OK;
+#else
+        return fail(NIG_ERR_UNSUPPORTED, "nig_tune: NIG_TUNE_DIAG_RING_FAULT exists in NIG_RING_SPIN_LIMIT test builds only%s");
+#endif
+    }
     if ((key != NIG_TUNE_SPLIT_BLOCKS && key != NIG_TUNE_WIDE_MIN_BLOCKS) || value < -1 || value >= (int64_t)nig::TUNE_UNSET)
         return fail(NIG_ERR_INVALID, "nig_tune: unknown key or value out of range%s");
     // -1 = back to "no explicit setting": every handle uses its own device's default again
@@ -373,6 +411,17 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     nig_layout_query(env, batch, flags, &h->lay);
     if (workspace) {
         if (((uintptr_t)workspace & 255u) != 0) { delete h; return fail(NIG_ERR_INVALID, "nig_create: workspace not 256-byte aligned%s"); }
+        // the step kernel updates the episode tally and the lifetime violation count with hardware atomics executed at the
+        // memory side: on host-pinned / fine-grained memory they would silently miscount
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        const hipError_t pe = hipPointerGetAttributes(&at, workspace);
+        if (pe != hipSuccess) { (void)hipGetLastError(); delete h; return fail(NIG_ERR_INVALID, "nig_create: workspace is not a device allocation (%s)", hipGetErrorString(pe)); }
+        if (at.type != hipMemoryTypeDevice || at.device != device) {
+            delete h;
+            return fail(NIG_ERR_INVALID, "nig_create: workspace must be ordinary device-local memory of `device` (hipMalloc / a torch CUDA tensor), "
+                                         "not host-pinned, managed or another device's memory%s");
+        }
         h->ws = (char *)workspace; h->owns_ws = false;
     } else {
         void *p = nullptr;
@@ -392,6 +441,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
                        L.off_tally >= 0 ? (double *)(h->ws + L.off_tally) : nullptr, L.ld, L.batch);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipMemsetAsync(h->ws + L.off_state, 0, (size_t)SPECS[env].state_dim * L.ld * 4, (hipStream_t)0);
+    if (le == hipSuccess) le = hipMemsetAsync(h->t_dev, 0, 256, (hipStream_t)0);      // launch counter of plans + the ring error word of test builds
     if (le == hipSuccess) le = hipStreamSynchronize((hipStream_t)0);
     if (le != hipSuccess) {
         if (h->owns_ws) (void)hipFree(h->ws);
@@ -590,7 +640,7 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
     launch_of(h->env)->rollout(out_mode, q, h->t + 1u, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
-    return NIG_OK;
+    return ring_check(h, st, "nig_rollout");
 }
 
 int nig_rollout(nig_handle *h, int32_t n_steps, const float *action_ring, int64_t ld_act, int64_t slot_stride,
@@ -663,7 +713,7 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
     launch_of(h->env)->policy(q, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());
     h->t += (uint32_t)n_steps;
-    return NIG_OK;
+    return ring_check(h, st, "nig_rollout_policy");
 }
 
 // Row of a 32x32 MFMA result tile held in register t by lane half hf (MI355X_MICROARCH / guide section 3).

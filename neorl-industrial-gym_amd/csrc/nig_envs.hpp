@@ -901,6 +901,9 @@ struct SpecPlant {
     __device__ static bool box_ok(const float (&s)[S], int c)
     {
         constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        // (the trees are seeded with the run's first row: a constraint over an EMPTY run would test that row against zero
+        // limits -- every plant has three non-empty constraints, spec_plants.py write_inc refuses anything else)
+        static_assert(P.ccount[0] >= 1 && P.ccount[1] >= 1 && P.ccount[2] >= 1, "SpecPlant: every box constraint covers at least one row");
         float mn = s[P.cfirst[c]], mx = mn;
 #pragma unroll
         for (int r = 0; r < S; ++r)

@@ -67,11 +67,14 @@ struct StepArgs {
     int n_en;                         // enabled built-in constraints = SafetyMetrics.total_constraints of every step (base.py:115)
     // host side only (which kernel form a launch takes, nig_tune): thresholds in effect for this handle's device
     uint32_t split_blocks, wide_min_blocks;
+    uint32_t *ring_err;               // device word a timed-out ring wait is reported in (NIG_RING_SPIN_LIMIT builds only; nig_ring.hpp)
 };
 // internal bit of StepArgs::hflags (above the public NIG_F_* bits): some lane of the handle may hold
 // NIG_CTR_DONE although the handle auto-resets (never reset, left out by reset(mask), set by
 // nig_set_state); cleared by a full nig_reset.  Lets the rollout kernel keep its no-freeze fast path.
 constexpr uint32_t HF_MAY_HOLD_DONE = 0x10000u;
+// test-only (NIG_RING_SPIN_LIMIT builds, nig_ring.hpp): producing roles stop posting after 7 steps
+constexpr uint32_t HF_DIAG_RING_FAULT = 0x20000u;
 
 // IndustrialEnv.step for one lane, entirely in registers (base.py:157-213): action clip, constraint
 // check on the pre-state and dynamics, then post_core = reward / penalties / termination on the

@@ -85,8 +85,9 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
             double *slot = ringd + (i & (L::K - 1)) * (L::SLOT_V4 * 2);
 #pragma unroll
             for (int k = 0; k < 23; ++k) slot[64 * k + lane] = z[k];
-            split_post(sync + 0, (uint32_t)i + 1u, lane);
+            NIG_RING_FAULT_GUARD(p.hflags, i) split_post(sync + 0, (uint32_t)i + 1u, lane);
         }
+        NIG_RING_REPORT(p.ring_err, sync, lane);
         return;
     }
     for (int i = 0; i < n; ++i) {
@@ -104,8 +105,9 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
         v4f *slot = ring + (i & (L::K - 1)) * L::SLOT_V4;
 #pragma unroll
         for (int j = 0; j < 6; ++j) slot[64 * j + lane] = z[j];
-        split_post(sync + 0, (uint32_t)i + 1u, lane);
+        NIG_RING_FAULT_GUARD(p.hflags, i) split_post(sync + 0, (uint32_t)i + 1u, lane);
     }
+    NIG_RING_REPORT(p.ring_err, sync, lane);
 }
 
 // NOISE: nig_rollout_noise -- the step's 23 draws are the reference's recorded float64 values (loaded from the caller's
@@ -462,6 +464,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         (p.ep_ret + base)[tid] = ret;
         if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
     }
+    if constexpr (PROD) NIG_RING_REPORT(p.ring_err, nz_sync, lane);
 }
 
 // The paired form's kernel: 256 lanes per block, 512 threads -- waves 0-3 step (pg_lds_rollout_body, PROD), waves 4-7

@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         if (i < n) integrate(in0, in1, i);
 #pragma unroll
         for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[lane] = s[k];
+        NIG_RING_REPORT(p.ring_err, sync, lane);
         return;
     }
 
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
             for (int k = 0; k < KS; ++k) hi[k * 64 + lane] = (float)nz[k];    // exact: the fast-mode noise IS a float (nig_envs.hpp)
 #pragma unroll
             for (int k = 0; k < A; ++k) hi[(KS + k) * 64 + lane] = a[k];
-            split_post(sync + 0, (uint32_t)j + 1u, lane);
+            NIG_RING_FAULT_GUARD(p.hflags, j) split_post(sync + 0, (uint32_t)j + 1u, lane);
             load_action(ab);                      // this register set's next use: local step j + LA
             pslot = (pslot + 1 == K) ? 0 : pslot + 1;
         };
@@ -253,6 +254,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         tail_k(std::integral_constant<int, 0>{}); tail_k(std::integral_constant<int, 1>{}); tail_k(std::integral_constant<int, 2>{});
         tail_k(std::integral_constant<int, 3>{}); tail_k(std::integral_constant<int, 4>{}); tail_k(std::integral_constant<int, 5>{});
         tail_k(std::integral_constant<int, 6>{});
+        NIG_RING_REPORT(p.ring_err, sync, lane);
         return;
     }
 
@@ -333,6 +335,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         (p.ep_ret + base)[lane] = (double)ret;
         if (lt.episodes > 0) lt.merge(p.tally + base + lane, p.ld, p.n_en);
     }
+    NIG_RING_REPORT(p.ring_err, sync, lane);
 }
 
 // whole blocks of 64*NP lanes, PAIRED start; the caller (launch_rollout_form) has checked that the form applies

@@ -98,9 +98,10 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
                 for (int k = 0; k < A; ++k) hi[(ROW_RA + k) * 64 + lane] = d.ra[k];
                 hi[ROW_MIX * 64 + lane] = d.wmix;
             }
-            split_post(sync + 0, (uint32_t)j + 1u, lane);
+            NIG_RING_FAULT_GUARD(p.hflags, j) split_post(sync + 0, (uint32_t)j + 1u, lane);
             pslot = (pslot + 1 == K) ? 0 : pslot + 1;
         }
+        NIG_RING_REPORT(p.ring_err, sync, lane);
         return;
     }
 
@@ -179,6 +180,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
                 (q.pid + base + (size_t)(A + j) * p.ld)[lane] = eprev[j];
             }
         }
+        NIG_RING_REPORT(p.ring_err, sync, lane);
         return;
     }
 
@@ -246,6 +248,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
         (p.ep_ret + base)[lane] = ret;
         if (lt.episodes > 0) lt.merge(p.tally + base + lane, p.ld, p.n_en);
     }
+    NIG_RING_REPORT(p.ring_err, sync, lane);
 }
 
 }  // namespace nig

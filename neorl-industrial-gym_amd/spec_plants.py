@@ -175,6 +175,10 @@ def emit_inc():
             G.append(_row(g, MAX_A))
         G += [_row([], MAX_A)] * (MAX_NP - np_)
         c = p["constraints"]
+        # SpecPlant::box_ok seeds its min / max trees with the run's first row: a constraint must cover at least one row, and
+        # the step template has exactly three constraints (csrc/nig_envs.hpp static_assert)
+        if len(c) != 3 or any(int(x[2]) < 1 for x in c):      # (name, first row, row count, lo, hi, penalty, critical)
+            raise ValueError(f"{p['name']}: a build-specified plant needs exactly three non-empty box constraints")
         fields = [
             f"{np_}, {na}",
             _row([y["y0"] for y in Y], MAX_NP), _row([y["sd0"] for y in Y], MAX_NP),

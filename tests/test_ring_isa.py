@@ -1,0 +1,195 @@
+"""not-gpu: the generated ISA of the cooperating-wave kernels keeps the LDS ring protocol's operations on the right side
+of its fences (csrc/nig_ring.hpp; ADVICE r02 / VERDICT r03 #5b).
+
+The rings exchange data between the waves of a block through plain LDS accesses ordered against a counter by (a) gfx950
+executing the DS operations of ONE wave in issue order and (b) wavefront-scope fences that pin the COMPILER's order:
+"write data, fence, write counter" on the producing side, "read counter, fence, read data" on the consuming side.  (a) is
+the hardware's; (b) is checked here on the assembly hipcc generates for the very sources and flags of the build, with
+comment-only markers at the fences (-DNIG_RING_MARKERS: the marker build holds the same DS instructions as the production
+one -- asserted below).  Per kernel (three-wave open loop for ChemicalReactor and RobotAssembly,
+three-wave closed loop, PowerGrid's paired form):
+  * a counter is written only inside a POST_BEGIN .. POST_END span, by one lane-masked ds_write_b32, and nothing else
+    touches LDS inside the span;
+  * the straight-line code leading up to a "produced" post (back to the previous marker) holds the slot's data WRITES,
+    the code leading up to a "slot released" post holds the consumer's data READS -- i.e. the data operations were not
+    moved below the counter write;
+  * the last LDS operation before a WAIT_END marker (behind the acquiring fence of a wait) is the counter read of its
+    spin loop: no data read was hoisted above the counter read it depends on.
+What this does NOT prove: the hardware rule (a) -- that is what the bit-exact GPU tests and the bounded-wait variant
+(tests/test_gpu_ring_limit.py) are for."""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "neorl-industrial-gym_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-w", "-S", "--cuda-device-only"]
+KERNELS = [   # (translation unit, mangled-name fragment, counters that publish data writes, counters that release slots after reads)
+    ("env_cr", "split_rollout_kernelINS_15ChemicalReactorELi3ELi4ELb0E", {0, 1}, {2}),
+    ("env_ra", "split_rollout_kernelINS_13RobotAssemblyELi3ELi4ELb0E", {0, 1}, {2}),
+    ("env_cr", "split_policy_kernelINS_15ChemicalReactorELi4E", {0, 1}, {2}),
+    ("env_pg", "rollout_pg_pair_kernelILi3ELb0E", {0}, {1}),
+]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    pytest.skip("hipcc not found")
+
+
+@pytest.fixture(scope="module")
+def listings():
+    hipcc = _hipcc()
+    tmp = tempfile.mkdtemp(prefix="nig_isa_")
+    tus = sorted({k[0] for k in KERNELS})
+
+    def one(job):
+        tu, marked = job
+        out = os.path.join(tmp, f"{tu}_{'mark' if marked else 'prod'}.s")
+        subprocess.check_call([hipcc] + FLAGS + (["-DNIG_RING_MARKERS"] if marked else []) + ["-o", out, os.path.join(CSRC, tu + ".hip")])
+        return (tu, marked), open(out).read().split("\n")
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return dict(ex.map(one, [(tu, m) for tu in tus for m in (True, False)]))
+
+
+def _kernel(lines, frag):
+    start = [i for i, l in enumerate(lines) if l.startswith("_ZN3nig") and frag in l and l.rstrip().endswith(":") or
+             (l.startswith("_ZN3nig") and frag in l and ": " in l and not l.startswith("\t"))]
+    assert start, frag
+    i = start[0]
+    j = i
+    while not lines[j].startswith(".Lfunc_end"):
+        j += 1
+    return lines[i + 1:j]
+
+
+def _offsets(text):
+    """immediate byte offsets of a DS instruction"""
+    offs = []
+    m = re.search(r"offset:(\d+)", text)
+    if m:
+        offs.append(int(m.group(1)))
+    scale = 256 if "st64" in text else (8 if "_b64" in text else 4)
+    for m in re.finditer(r"offset[01]:(\d+)", text):
+        offs.append(int(m.group(1)) * scale)
+    return offs or [0]
+
+
+def _program(body):
+    """(instructions, successors, predecessors): one entry per instruction / marker, control flow from labels and branches."""
+    ins, labels = [], {}
+    for l in body:
+        t = l.strip()
+        if not t:
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            labels[t.split(":")[0]] = len(ins)
+        elif t.startswith("; NIG_RING_MARK"):
+            ins.append(("mark", t.split()[-1], None))
+        elif l.startswith("\t") and not t.startswith((".", ";")):
+            op = t.split()[0]
+            if op.startswith("ds_"):
+                ins.append(("ds", op, _offsets(t)))
+            elif op in ("s_branch",) or op.startswith("s_cbranch"):
+                ins.append(("br", op, t.split()[-1]))
+            elif op == "s_endpgm":
+                ins.append(("end", op, None))
+            elif op == "s_barrier":
+                ins.append(("barrier", op, None))
+            else:
+                ins.append(("op", op, None))
+    succ = [[] for _ in ins]
+    for k, e in enumerate(ins):
+        if e[0] == "br":
+            succ[k].append(labels[e[2]])
+            if e[1] != "s_branch" and k + 1 < len(ins):
+                succ[k].append(k + 1)
+        elif e[0] != "end" and k + 1 < len(ins):
+            succ[k].append(k + 1)
+    pred = [[] for _ in ins]
+    for k, ss in enumerate(succ):
+        for t_ in ss:
+            pred[t_].append(k)
+    return ins, succ, pred
+
+
+def _walk(start_nodes, edges, stop):
+    """every node reachable from start_nodes along `edges`, not expanding nodes for which stop(node) holds (they are
+    returned in `hit`)"""
+    seen, hit, todo = set(), set(), list(start_nodes)
+    while todo:
+        k = todo.pop()
+        if k in seen:
+            continue
+        seen.add(k)
+        if stop(k):
+            hit.add(k)
+            continue
+        todo.extend(edges[k])
+    return seen - hit, hit
+
+
+def _n_instructions(body):
+    return sum(1 for l in body if l.startswith("\t") and not l.strip().startswith((".", ";")))
+
+
+@pytest.mark.parametrize("tu,frag,produced,released", KERNELS, ids=[k[1][:40] for k in KERNELS])
+def test_ring_operations_stay_on_their_side_of_the_fences(listings, tu, frag, produced, released):
+    marked = _kernel(listings[(tu, True)], frag)
+    prod = _kernel(listings[(tu, False)], frag)
+    # the markers are comments (and scheduling boundaries: a handful of scalar moves may differ): the marker build runs the
+    # production build's LDS program -- the same DS instructions, mnemonic by mnemonic -- at the same size within 1 %
+    ds_of = lambda body: sorted(l.split()[0] for l in body if l.strip().startswith("ds_"))
+    assert ds_of(marked) == ds_of(prod)
+    assert abs(_n_instructions(marked) - _n_instructions(prod)) <= 0.01 * _n_instructions(prod)
+    ins, succ, pred = _program(marked)
+    first_barrier = next(k for k, e in enumerate(ins) if e[0] == "barrier")
+    # the sync block is zeroed before the first block barrier: that store's offset is where the counters live
+    init = [e for e in ins[:first_barrier] if e[0] == "ds" and e[1] == "ds_write_b32"]
+    assert init, "no counter initialisation found"
+    off_sync = init[-1][2][0]
+    counters = {off_sync + 4 * k: k for k in range(4)}
+
+    def counter_of(k):
+        e = ins[k]
+        return counters.get(e[2][0]) if (e[0] == "ds" and e[1] in ("ds_write_b32", "ds_read_b32") and len(e[2]) == 1) else None
+
+    is_mark = lambda k: ins[k][0] == "mark"
+    begins = [k for k, e in enumerate(ins) if e == ("mark", "POST_BEGIN", None)]
+    wait_ends = [k for k, e in enumerate(ins) if e == ("mark", "WAIT_END", None)]
+    assert len(begins) >= 2 and len(wait_ends) >= 2, (len(begins), len(wait_ends))
+    in_span = set()
+    for b in begins:
+        # forward from the marker to the POST_END markers: the span holds ONE LDS operation, the counter write
+        inside, ends = _walk(succ[b], succ, is_mark)
+        assert ends and all(ins[k][1] == "POST_END" for k in ends), [ins[k] for k in ends]
+        assert not any(ins[k][0] == "end" for k in inside), "a post span runs into the end of the program"
+        ds = [k for k in inside if ins[k][0] == "ds"]
+        assert len(ds) == 1 and ins[ds[0]][1] == "ds_write_b32" and counter_of(ds[0]) is not None, [ins[k] for k in ds]
+        in_span.update(ds)
+        c = counter_of(ds[0])
+        # backward from the marker to the previous markers: what the post publishes / releases was issued BEFORE the fence
+        before, _ = _walk(pred[b], pred, lambda k: is_mark(k) or k <= first_barrier)
+        data = [ins[k] for k in before if ins[k][0] == "ds" and counter_of(k) is None]
+        if c in produced:
+            assert any(e[1].startswith("ds_write") for e in data), (c, "a 'produced' post without the slot's data writes before its fence")
+        else:
+            assert c in released, c
+            assert any(e[1].startswith("ds_read") for e in data), (c, "a 'released' post without the consumer's reads before its fence")
+    # a counter is written nowhere else (after the initialisation)
+    stray = [ins[k] for k in range(first_barrier, len(ins)) if ins[k][0] == "ds" and ins[k][1] == "ds_write_b32"
+             and counter_of(k) is not None and k not in in_span]
+    assert not stray, stray
+    for w in wait_ends:
+        # backward from the marker behind a wait's acquiring fence: on every path the nearest LDS operation is the spin
+        # loop's counter read -- no ring data was read before the counter it depends on
+        _, first_ds = _walk(pred[w], pred, lambda k: ins[k][0] == "ds" or is_mark(k))
+        assert first_ds and all(ins[k][0] == "ds" and ins[k][1] == "ds_read_b32" and counter_of(k) is not None for k in first_ds), \
+            [ins[k] for k in first_ds]
