@@ -709,6 +709,7 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
     q.pid = (h->pol_host.kind == NIG_POLICY_PID) ? h->pid_mem : nullptr;
     q.obs_out = obs_out; q.obs_step_stride = (uint64_t)obs_step_stride;
     q.act_out = act_out; q.ld_act_out = (uint32_t)ld_act; q.act_step_stride = (uint64_t)act_step_stride;
+    q.pol_kind = h->pol_host.kind;
     hipStream_t st = (hipStream_t)stream;
     launch_of(h->env)->policy(q, grid_for(h->B), st);
     HIP_TRY(hipGetLastError());

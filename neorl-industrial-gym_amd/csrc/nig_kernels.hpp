@@ -1012,6 +1012,16 @@ __global__ void __launch_bounds__(BLOCK, Env::ROLLOUT_WAVES) rollout_kernel(cons
 template <class E, class = void> struct wide_rollout : std::integral_constant<int, 0> {};
 template <class E> struct wide_rollout<E, std::void_t<decltype(E::WIDE_ROLLOUT_BLOCK)>> : std::integral_constant<int, E::WIDE_ROLLOUT_BLOCK> {};
 
+// (declared here for nig_pg_lds.hpp's closed-loop form; defined with the policy kernels below)
+// The policy's random draws of one step: they depend on the lane's key only, not on the observation, so the
+// cooperating-wave forms (nig_split_policy.hpp, nig_pg_lds.hpp) produce them ahead of the step that consumes them.
+template <int A>
+struct PolicyDraws { float z[A], h[A], ra[A], wmix; };
+template <class Env> __device__ __forceinline__ void policy_draws(const nig_policy *__restrict__ P, const RngKey &key, PolicyDraws<Env::A> &d);
+template <int A, class PV> __device__ __forceinline__ void policy_switches(const PV *__restrict__ P, bool &any_sigma, bool &any_half, bool &mix);
+template <class Env, class PV> __device__ __forceinline__ void policy_affine(const PV *__restrict__ P, const float (&obs)[Env::S], float (&u)[Env::A]);
+template <class Env, class PV> __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A]);
+
 }  // namespace nig
 #include "nig_ring.hpp"
 #include "nig_pg_lds.hpp"
@@ -1067,12 +1077,9 @@ struct PolicyArgs {
     float *obs_out; uint64_t obs_step_stride;                        // row-major [B][S] per step, pre-step obs
     float *act_out; uint32_t ld_act_out; uint64_t act_step_stride;   // [A][ld] per step
     uint32_t block0;            // first 256-lane block of this launch (whole blocks and a ragged last block are separate launches)
+    int32_t pol_kind;           // host copy of pol->kind (NIG_POLICY_*): selects the kernel form, never read on the device
 };
 
-// The policy's random draws of one step: they depend on the lane's key only, not on the observation, so the
-// three-wave form (nig_split.hpp) produces them ahead of the step that consumes them.
-template <int A>
-struct PolicyDraws { float z[A], h[A], ra[A], wmix; };
 
 // Register copy of the policy fields an env of this size reads, for a wave that evaluates the feedback law on its
 // critical path (the integrator of nig_split_policy.hpp): read in place from LDS, every observation column is one
@@ -1141,34 +1148,29 @@ __device__ __forceinline__ void policy_draws(const nig_policy *__restrict__ P, c
     }
 }
 
-// feedback law on the observation + the draws + the policy's own clip (include/nig.h "nig-policy-v1")
+// feedback law on the observation + the draws + the policy's own clip (include/nig.h "nig-policy-v1"), in its two halves:
+// policy_affine = u_j = b_j + sum_k Wt[k][j] obs[k] (ascending k, zero columns skipped), policy_finish = exploration
+// noise, epsilon-mix and the policy's clip.  policy_apply composes them (PID: its own law, then policy_finish).
 template <class Env, class PV>
-__device__ __forceinline__ void policy_apply(const PV *__restrict__ P, const float (&obs)[Env::S],
-                                             const PolicyDraws<Env::A> &d, float (&integ)[Env::A], float (&eprev)[Env::A],
-                                             float (&u)[Env::A])
+__device__ __forceinline__ void policy_affine(const PV *__restrict__ P, const float (&obs)[Env::S], float (&u)[Env::A])
 {
     constexpr int S = Env::S, A = Env::A;
-    if (P->kind == NIG_POLICY_PID) {               // baseline_agents.py:61-80
-        const float kp = P->kp, ki = P->ki, kd = P->kd;
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float e = P->setpoint[j] - obs[j];
-            integ[j] = integ[j] + e;
-            u[j] = (kp * e + ki * integ[j]) + kd * (e - eprev[j]);
-            eprev[j] = e;
-        }
-    } else {
+    for (int j = 0; j < A; ++j) u[j] = P->b[j];
+    const uint32_t cm = P->colmask;
 #pragma unroll
-        for (int j = 0; j < A; ++j) u[j] = P->b[j];
-        const uint32_t cm = P->colmask;
+    for (int k = 0; k < S; ++k) {
+        if (cm & (1u << k)) {                  // wave-uniform: whole zero columns are skipped
 #pragma unroll
-        for (int k = 0; k < S; ++k) {
-            if (cm & (1u << k)) {                  // wave-uniform: whole zero columns are skipped
-#pragma unroll
-                for (int j = 0; j < A; ++j) u[j] = u[j] + P->Wt[k][j] * obs[k];
-            }
+            for (int j = 0; j < A; ++j) u[j] = u[j] + P->Wt[k][j] * obs[k];
         }
     }
+}
+
+template <class Env, class PV>
+__device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A])
+{
+    constexpr int A = Env::A;
     bool any_sigma, any_half, mix;
     policy_switches<A>(P, any_sigma, any_half, mix);
     if (any_sigma) {
@@ -1192,6 +1194,27 @@ __device__ __forceinline__ void policy_apply(const PV *__restrict__ P, const flo
         x = (x > hi) ? hi : x;
         u[j] = x;
     }
+}
+
+template <class Env, class PV>
+__device__ __forceinline__ void policy_apply(const PV *__restrict__ P, const float (&obs)[Env::S],
+                                             const PolicyDraws<Env::A> &d, float (&integ)[Env::A], float (&eprev)[Env::A],
+                                             float (&u)[Env::A])
+{
+    constexpr int A = Env::A;
+    if (P->kind == NIG_POLICY_PID) {               // baseline_agents.py:61-80
+        const float kp = P->kp, ki = P->ki, kd = P->kd;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float e = P->setpoint[j] - obs[j];
+            integ[j] = integ[j] + e;
+            u[j] = (kp * e + ki * integ[j]) + kd * (e - eprev[j]);
+            eprev[j] = e;
+        }
+    } else {
+        policy_affine<Env>(P, obs, u);
+    }
+    policy_finish<Env>(P, d, u);
 }
 
 // The one-wave kernel's form of the same policy: draws interleaved with their use (shorter live ranges than
@@ -1907,6 +1930,20 @@ static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
             PolicyArgs r = q;
             r.block0 = 0;
             hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(n_full), dim3(192 * (BLOCK / 64)), 0, st, r);
+            if (q.s.B % BLOCK) { r.block0 = n_full; hipLaunchKernelGGL((rollout_policy_kernel<Env>), dim3(1), dim3(BLOCK), 0, st, r); }
+            return;
+        }
+    }
+    if constexpr (pair_rollout<Env>::value) {
+        // PowerGrid, affine policies, batches of at most one 256-lane block per compute unit (the open loop's paired-form
+        // regime, nig_tune(NIG_TUNE_SPLIT_BLOCKS)): stepping + producer wave per 64 lanes (rollout_pg_pair_policy_kernel);
+        // a ragged last block on the one-wave kernel.  PID policies keep their memory in registers: one-wave kernel.
+        const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+        const unsigned n_full = q.s.B / BLOCK;
+        if (plain && q.pol_kind == NIG_POLICY_AFFINE && n_full > 0 && q.s.split_blocks != 0 && n_full <= q.s.split_blocks) {
+            PolicyArgs r = q;
+            r.block0 = 0;
+            hipLaunchKernelGGL((rollout_pg_pair_policy_kernel<PolicyArgs>), dim3(n_full), dim3(512), 0, st, r);
             if (q.s.B % BLOCK) { r.block0 = n_full; hipLaunchKernelGGL((rollout_policy_kernel<Env>), dim3(1), dim3(BLOCK), 0, st, r); }
             return;
         }

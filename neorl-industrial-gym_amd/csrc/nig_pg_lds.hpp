@@ -50,11 +50,20 @@ struct PgLds {
 // were no faster (711 / 676 us).
 // NOISE (nig_rollout_noise: the reference's recorded float64 draws instead of the generator's): a slot holds the step's 23
 // draws as doubles, [draw][lane], because power_grid.py:136-144 adds them in float64.
-template <bool NOISE>
+// POLICY (rollout_pg_pair_policy_kernel: the closed loop, nig_rollout_policy): a slot also carries the on-device policy's own
+// random draws of the step -- exploration normals z[8], uniform perturbations h[8], the epsilon-mix's uniform action ra[8]
+// and its mixing draw: 25 float rows -- and the block keeps a copy of the policy struct.
+template <bool NOISE, bool POLICY = false>
 struct PgPairLdsT {
     static constexpr int K = 2;                                   // ring slots (steps) per pair
-    static constexpr int SLOT_V4 = NOISE ? 23 * 64 / 2 : 6 * 64;  // float4 per slot: [generator block][lane] (NOISE: 23 x 64 doubles)
-    static constexpr int OFF_NZ = (PgLds<256>::BYTES + 15) / 16 * 16;
+    static constexpr int DRAW_ROWS = 25;                          // POLICY: z[8], h[8], ra[8], wmix
+    static constexpr int NZ_V4 = NOISE ? 23 * 64 / 2 : 6 * 64;    // float4 of a slot's process noise: [generator block][lane] (NOISE: 23 x 64 doubles)
+    static constexpr int SLOT_V4 = NZ_V4 + (POLICY ? DRAW_ROWS * 16 : 0);
+    static constexpr int OFF_POL = (PgLds<256>::BYTES + 15) / 16 * 16;
+    // POLICY: behind the policy struct, a dense 16-byte-aligned copy of its feedback matrix, [32 state columns][8 actions]
+    // (the struct's rows are 40 bytes apart: no ds_read_b128 there)
+    static constexpr int OFF_WD = OFF_POL + (POLICY ? (int)((sizeof(nig_policy) + 15) / 16 * 16) : 0);
+    static constexpr int OFF_NZ = OFF_WD + (POLICY ? 32 * 8 * 4 : 0);
     static constexpr int OFF_SYNC = OFF_NZ + 4 * K * SLOT_V4 * 16;     // uint32 [4 pairs][4]: {produced, consumed}
     static constexpr int BYTES = OFF_SYNC + 4 * 16;
     static_assert(BYTES <= 160 * 1024, "LDS of one CU");
@@ -62,22 +71,73 @@ struct PgPairLdsT {
 using PgPairLds = PgPairLdsT<false>;
 
 // producer wave `wave` (0-3) of the block: lanes base + 64 wave .. + 63, local steps [0, n)
-template <bool NOISE = false>
-__device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uint32_t base, unsigned char *smem, const unsigned wave, const unsigned lane)
+// Register copy of the policy fields the closed loop reads every step besides the feedback matrix (same field names as
+// nig_policy: policy_finish takes either).  Read in place from LDS, every field was an exposed ds_read round trip per step.
+struct PgPolicyHead {
+    uint32_t colmask;
+    float b[8], sigma[8], half_range[8], p_uniform, uniform_range, clip_lo, clip_hi;
+    __device__ __forceinline__ void load(const nig_policy &P)
+    {
+        colmask = __builtin_amdgcn_readfirstlane(P.colmask);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b[j] = P.b[j]; sigma[j] = P.sigma[j]; half_range[j] = P.half_range[j]; }
+        p_uniform = P.p_uniform; uniform_range = P.uniform_range; clip_lo = P.clip_lo; clip_hi = P.clip_hi;
+    }
+};
+
+// policy_affine for PowerGrid's closed loop: u_j = b_j + sum_k Wt[k][j] obs[k], ascending k, zero columns skipped -- the same
+// operations on the same values as policy_affine (nig_kernels.hpp), with the matrix read from the dense LDS copy EIGHT
+// COLUMNS AHEAD: sixteen ds_read_b128 in flight, one wait, then the columns' multiply-adds behind wave-uniform tests of the
+// column mask.  (Read column by column inside those tests, every active column cost two exposed LDS round trips: 34 per step
+// for the "expert" law's 17 columns -- +1.9 us per step, which made the paired closed loop no faster than the one-wave kernel.)
+__device__ __forceinline__ void pg_policy_affine(const PgPolicyHead &H, const v4f *__restrict__ wd, const float (&obs)[32], float (&u)[8])
 {
-    using L = PgPairLdsT<NOISE>;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = H.b[j];
+    const uint32_t cm = H.colmask;
+#pragma unroll
+    for (int q8 = 0; q8 < 4; ++q8) {
+        if ((cm >> (8 * q8)) & 0xFFu) {            // wave-uniform: any column of this quarter in use?
+            v4f c[8][2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { c[k][0] = wd[(8 * q8 + k) * 2]; c[k][1] = wd[(8 * q8 + k) * 2 + 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (cm & (1u << (8 * q8 + k))) {   // wave-uniform: whole zero columns are skipped (as policy_affine)
+                    const float o = obs[8 * q8 + k];
+                    u[0] = u[0] + c[k][0].x * o; u[1] = u[1] + c[k][0].y * o; u[2] = u[2] + c[k][0].z * o; u[3] = u[3] + c[k][0].w * o;
+                    u[4] = u[4] + c[k][1].x * o; u[5] = u[5] + c[k][1].y * o; u[6] = u[6] + c[k][1].z * o; u[7] = u[7] + c[k][1].w * o;
+                }
+            }
+        }
+    }
+}
+
+template <class QA> __device__ __forceinline__ int arg_it0(const QA &q)
+{
+    if constexpr (std::is_same<QA, RolloutArgs>::value) return q.it0; else return 0;     // (closed-loop launches start at call step 0)
+}
+
+template <bool NOISE = false, bool POLICY = false, class QA = RolloutArgs>
+__device__ __forceinline__ void pg_pair_producer(const QA &q, const uint32_t base, unsigned char *smem, const unsigned wave, const unsigned lane)
+{
+    using L = PgPairLdsT<NOISE, POLICY>;
+    static_assert(!(NOISE && POLICY), "recorded draws exist for the open loop only");
+    [[maybe_unused]] const nig_policy *const pol = reinterpret_cast<const nig_policy *>(smem + L::OFF_POL);
     const float4 *const s_probit = reinterpret_cast<const float4 *>(smem + PgLds<256>::OFF_PROBIT);
     v4f *const ring = reinterpret_cast<v4f *>(smem + L::OFF_NZ) + wave * (L::K * L::SLOT_V4);
     lds_u32_t *const sync = (lds_u32_t *)(smem + L::OFF_SYNC) + wave * 4;
     const StepArgs &p = q.s;
-    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off + (uint32_t)q.it0;      // local step i uses t_base + i + 1
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off + (uint32_t)arg_it0(q);      // local step i uses t_base + i + 1
     const uint64_t gi = p.env0 + (uint64_t)(base + wave * 64u + lane);
-    const int n = q.n_steps - q.it0;
+    const int n = q.n_steps - arg_it0(q);
     uint32_t freed = 0u;                                           // slots the stepping wave is known to be done with
+    [[maybe_unused]] bool any_sigma = false, any_half = false, mix = false;    // wave-uniform switches of the policy
+    if constexpr (POLICY) policy_switches<PowerGrid::A>(pol, any_sigma, any_half, mix);
     if constexpr (NOISE) {                         // the step's recorded draws, loaded where the generator would have produced them
         double *const ringd = reinterpret_cast<double *>(ring);
         for (int i = 0; i < n; ++i) {
-            const double *nzr = p.step_noise + (size_t)(q.it0 + i) * q.nz_step_stride + base + wave * 64u;
+            const double *nzr = p.step_noise + (size_t)(arg_it0(q) + i) * q.nz_step_stride + base + wave * 64u;
             double z[23];
 #pragma unroll
             for (int k = 0; k < 23; ++k) z[k] = (nzr + (size_t)k * p.ld_noise)[lane];
@@ -101,10 +161,28 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
             if (j < 5) w.w = probit_eval(probit_fetch(x.w, s_probit));     // z[23] does not exist
             z[j] = w;
         }
+        [[maybe_unused]] PolicyDraws<PowerGrid::A> d;
+        if constexpr (POLICY) policy_draws<PowerGrid>(pol, key, d);      // the policy's own draws of this step: a function of the key alone
         if (freed + (uint32_t)L::K < (uint32_t)i + 1u) freed = split_wait(sync + 1, (uint32_t)(i + 1 - L::K));   // the slot's previous use
         v4f *slot = ring + (i & (L::K - 1)) * L::SLOT_V4;
 #pragma unroll
         for (int j = 0; j < 6; ++j) slot[64 * j + lane] = z[j];
+        if constexpr (POLICY) {
+            float *dr = reinterpret_cast<float *>(slot + L::NZ_V4) + lane;       // [DRAW_ROWS][64]
+            if (any_sigma) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dr[k * 64] = d.z[k];
+            }
+            if (any_half) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dr[(8 + k) * 64] = d.h[k];
+            }
+            if (mix) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dr[(16 + k) * 64] = d.ra[k];
+                dr[24 * 64] = d.wmix;
+            }
+        }
         NIG_RING_FAULT_GUARD(p.hflags, i) split_post(sync + 0, (uint32_t)i + 1u, lane);
     }
     NIG_RING_REPORT(p.ring_err, sync, lane);
@@ -113,13 +191,20 @@ __device__ __forceinline__ void pg_pair_producer(const RolloutArgs &q, const uin
 // NOISE: nig_rollout_noise -- the step's 23 draws are the reference's recorded float64 values (loaded from the caller's
 // rows, or read from the producer's slot in the paired form) and enter through the float64 adds of power_grid.py:136-144
 // (PowerGrid::dynamics' parity branch); a finishing lane's image row is rewritten with PowerGrid::init(recorded draws).
-template <int OUT, int BLK, bool PROD = false, bool NOISE = false>
-__device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
+// POLICY (paired form only; QA = PolicyArgs): the closed loop of nig_rollout_policy -- the action is the installed affine
+// policy of the lane's observation (policy_affine on the image's pre-step values, ascending state index as everywhere;
+// the policy's own draws come from the producer's slot: policy_finish), the optional outputs are those of
+// rollout_policy_kernel (the observation acted on, row-major through the image's transposed reads; the policy's action
+// rows; reward + flag rows), run-time switches as there.  Bit-identical to rollout_policy_kernel (tests/test_gpu_split.py).
+template <int OUT, int BLK, bool PROD = false, bool NOISE = false, bool POLICY = false, class QA = RolloutArgs>
+__device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t base, unsigned char *smem)
 {
     using Env = PowerGrid;
     constexpr int S = Env::S, A = Env::A;
     using Lds = PgLds<BLK>;
-    using PgPairLds = PgPairLdsT<NOISE>;
+    using PgPairLds = PgPairLdsT<NOISE, POLICY>;
+    static_assert(!POLICY || (PROD && OUT == 0 && !NOISE), "closed loop: the paired form, outputs as run-time switches");
+    [[maybe_unused]] const nig_policy *const pol = reinterpret_cast<const nig_policy *>(smem + PgPairLds::OFF_POL);
     static_assert(!PROD || BLK == 256, "the paired form runs 256-lane blocks");
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + Lds::OFF_PROBIT);
     if constexpr (!PROD) {                         // (paired form: the kernel staged the table with all its waves)
@@ -151,7 +236,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
     LaneTally lt;
     lt.clear();
 
-    const float *ring = p.actions + base;
+    [[maybe_unused]] const float *ring = p.actions + base;
     // ONE action register set: the action of step it + 1 is loaded into it as soon as step it has consumed its own
     // (clip, generation update, the reward's action term: the first ~80 instructions of a step), i.e. a whole step
     // (~1 200 instructions, four waves sharing the SIMD) before it is used.  The wait for it is in order with the stores
@@ -159,22 +244,75 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
     // envs' steps are shorter and run at one or two waves per SIMD.)
     constexpr int DEPTH = 1;
     float buf[DEPTH][A];
-    int slot = q.it0 % q.ring_len;
-    const float *act_next;
-    float *rew_row = p.reward ? p.reward + base + (size_t)q.it0 * q.out_stride : nullptr;
-    uint32_t *fl_row = p.flags ? p.flags + base + (size_t)q.it0 * q.out_stride : nullptr;
+    [[maybe_unused]] int slot = 0;
+    if constexpr (!POLICY) slot = q.it0 % q.ring_len;
+    [[maybe_unused]] const float *act_next = nullptr;
+    const int it0 = arg_it0(q);
+    float *rew_row = p.reward ? p.reward + base + (size_t)it0 * q.out_stride : nullptr;
+    uint32_t *fl_row = p.flags ? p.flags + base + (size_t)it0 * q.out_stride : nullptr;
     float *obs_row = nullptr;
     // (the wave's first lane through readfirstlane: the row pointer is wave-uniform, and only then does the compiler keep it
     // in scalar registers; see rollout_body)
     if constexpr (OUT == 3)
         obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + (size_t)(base + __builtin_amdgcn_readfirstlane(tid & ~63u)) * S;
     if constexpr (OUT == 2) obs_row = q.obs_out + (size_t)q.it0 * q.obs_step_stride + base;
+    if constexpr (POLICY) {                        // the observation the policy acts on, row-major [n_steps][B][S] (optional)
+        if (q.obs_out) obs_row = q.obs_out + (size_t)(base + __builtin_amdgcn_readfirstlane(tid & ~63u)) * S;
+    }
+    [[maybe_unused]] float *act_row = nullptr;     // POLICY: the policy's action rows [n_steps][A][ld] (optional)
+    if constexpr (POLICY) { if (q.act_out) act_row = q.act_out + base; }
+    [[maybe_unused]] bool any_sigma = false, any_half = false, mix = false;
+    [[maybe_unused]] PgPolicyHead head;
+    [[maybe_unused]] const v4f *const wd = reinterpret_cast<const v4f *>(smem + PgPairLds::OFF_WD);
+    if constexpr (POLICY) { policy_switches<A>(pol, any_sigma, any_half, mix); head.load(*pol); }
     const unsigned rd = (lane & 7u) * 8u + (lane >> 3);             // transposed read: image float4 64 j + rd = row-major float4 64 j + lane
 
     auto one_step = [&](float (&abuf)[A], const int it) __attribute__((always_inline)) {
         float a[A];
+        [[maybe_unused]] const int itl0 = it - it0;                  // local step: the producer's slot index
+        [[maybe_unused]] float obs[S];                               // POLICY: the pre-step values the policy acts on (and the step then uses)
+        if constexpr (POLICY) {
+            // ---- action = policy(observation): the feedback law on the image's pre-step values, then the producer's draws
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { const v4f w = mine[8 * g]; obs[4 * g] = w.x; obs[4 * g + 1] = w.y; obs[4 * g + 2] = w.z; obs[4 * g + 3] = w.w; }
+            if (obs_row != nullptr) {              // (wave-uniform) the 64 observation rows in lane-contiguous order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                v4f *oo = reinterpret_cast<v4f *>(obs_row);
+                v4f tv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = img[64 * j + rd];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, tv[j]);
+                obs_row += q.obs_step_stride;
+            }
+            pg_policy_affine(head, wd, obs, a);
+            if (nz_seen < (uint32_t)itl0 + 1u) nz_seen = split_wait(nz_sync + 0, (uint32_t)itl0 + 1u);
+            const float *dr = reinterpret_cast<const float *>(nz_ring + (itl0 & (PgPairLds::K - 1)) * PgPairLds::SLOT_V4 + PgPairLds::NZ_V4) + lane;
+            PolicyDraws<A> d;
+            if (any_sigma) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.z[k] = dr[k * 64];
+            }
+            if (any_half) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.h[k] = dr[(8 + k) * 64];
+            }
+            if (mix) {
+#pragma unroll
+                for (int k = 0; k < A; ++k) d.ra[k] = dr[(16 + k) * 64];
+                d.wmix = dr[24 * 64];
+            }
+            policy_finish<Env>(&head, d, a);
+            if (act_row != nullptr) {              // the policy's action, before the env's own clip (as rollout_policy_kernel)
+#pragma unroll
+                for (int j = 0; j < A; ++j) stream_store(act_row + j * q.ld_act_out + tid, a[j]);
+                act_row += q.act_step_stride;
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = abuf[k];
+        }
         clip_action<Env, float>(a);
         const RngKey key = make_key(gi, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit);
         // ---- generation, load sum, frequency (state values 0, 9 .. 24) --------------------------------------------
@@ -183,12 +321,17 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         double er;
         uint32_t vb;
         {
-            const v4f g0 = mine[0], g1 = mine[8], g2 = mine[16], g3 = mine[24], g4 = mine[32], g5 = mine[40], g6 = mine[48];
             float s[S];                            // pre-step values, as far as violated() and the dynamics read them
+            if constexpr (POLICY) {                // (already read for the policy)
+#pragma unroll
+                for (int k = 0; k < 25; ++k) s[k] = obs[k];
+            } else {
+            const v4f g0 = mine[0], g1 = mine[8], g2 = mine[16], g3 = mine[24], g4 = mine[32], g5 = mine[40], g6 = mine[48];
             s[0] = g0.x;
             s[1] = g0.y; s[2] = g0.z; s[3] = g0.w; s[4] = g1.x; s[5] = g1.y; s[6] = g1.z; s[7] = g1.w; s[8] = g2.x;
             s[9] = g2.y; s[10] = g2.z; s[11] = g2.w; s[12] = g3.x; s[13] = g3.y; s[14] = g3.z; s[15] = g3.w; s[16] = g4.x;
             s[17] = g4.y; s[18] = g4.z; s[19] = g4.w; s[20] = g5.x; s[21] = g5.y; s[22] = g5.z; s[23] = g5.w; s[24] = g6.x;
+            }
 #pragma unroll
             for (int k = 25; k < S; ++k) s[k] = 0.0f;      // line flows: read by nothing before their own update
             vb = Env::violated(s, a) & p.cmask;            // base.py:170 on the pre-state, clipped action
@@ -219,18 +362,21 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
             }
             ngen7 = ngen[7];
             // refill this action register set (step it + DEPTH), issued before the step's stores: see rollout_body
+            if constexpr (!POLICY) {
 #pragma unroll
             for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
             slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
             act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------
-            [[maybe_unused]] const int itl = it - q.it0;                 // local step: the producer's slot index
+            [[maybe_unused]] const int itl = it - it0;                   // local step: the producer's slot index
             [[maybe_unused]] const v4f *const nzs = nz_ring + (itl & (PgPairLds::K - 1)) * PgPairLds::SLOT_V4;
             u32x4 x = {0u, 0u, 0u, 0u};
             // NOISE: draw k of this step, float64 -- from the producer's slot (paired form) or the caller's rows
             [[maybe_unused]] const double *const nzd_lds = reinterpret_cast<const double *>(nzs) + lane;
-            [[maybe_unused]] const double *const nzd_glb = NOISE ? p.step_noise + (size_t)it * q.nz_step_stride + base + tid : nullptr;
+            [[maybe_unused]] const double *nzd_glb = nullptr;
+            if constexpr (NOISE) nzd_glb = p.step_noise + (size_t)it * q.nz_step_stride + base + tid;
             [[maybe_unused]] auto nzd = [&](int k) __attribute__((always_inline)) -> double {
                 if constexpr (PROD) return nzd_lds[64 * k];
                 else return (nzd_glb + (size_t)k * p.ld_noise)[0];
@@ -288,6 +434,10 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
                 stream_store(rew_row + tid, (float)res.reward);
                 stream_store(fl_row + tid, pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u));
                 rew_row += q.out_stride; fl_row += q.out_stride;
+            }
+            if constexpr (POLICY) {                // run-time switches, as in rollout_policy_kernel (either may be absent)
+                if (rew_row) { stream_store(rew_row + tid, (float)res.reward); rew_row += q.out_stride; }
+                if (fl_row) { stream_store(fl_row + tid, pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u)); fl_row += q.out_stride; }
             }
             if (done) {                            // (lt.viol doubles as the lifetime violation count: two registers less)
                 if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
@@ -435,6 +585,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         }
     };
 
+    if constexpr (!POLICY) {
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
         const float *nx = ring + (size_t)slot * q.slot_stride;
@@ -443,6 +594,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
     }
     act_next = ring + (size_t)slot * q.slot_stride;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);            // prologue loads drained here, not in the loop header (rollout_body)
 #ifdef NIG_DIAG_PG_STAGGER             // (diagnostic builds only: start the four waves of a SIMD a quarter step apart)
     {
@@ -450,7 +602,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const RolloutArgs &q, const 
         for (unsigned k = 0; k < ph * NIG_DIAG_PG_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
     }
 #endif
-    int it = q.it0;
+    int it = it0;
     for (; it < q.n_steps; ++it) one_step(buf[0], it);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -482,6 +634,31 @@ __global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutAr
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= 4u) pg_pair_producer<NOISE>(q, base, smem, wave - 4u, threadIdx.x & 63u);
     else pg_lds_rollout_body<OUT, 256, true, NOISE>(q, base, smem);
+}
+
+// The paired form of the CLOSED loop (nig_rollout_policy, affine policies): as above, the producers also draw the policy's
+// own random numbers of the step, the stepping waves evaluate the feedback law on their image.  QA = PolicyArgs (a template
+// parameter only because that type is defined after this header); q.block0 counts 256-lane blocks.
+template <class QA>
+__global__ void __launch_bounds__(512, 2) rollout_pg_pair_policy_kernel(const QA q)
+{
+    using PL = PgPairLdsT<false, true>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PL::BYTES];
+    float4 *const s_probit = reinterpret_cast<float4 *>(smem + PgLds<256>::OFF_PROBIT);
+    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += 512) s_probit[i_] = NIG_PROBIT[i_];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem + PL::OFF_POL);
+        for (unsigned i_ = threadIdx.x; i_ < sizeof(nig_policy) / 4; i_ += 512u) dst[i_] = src[i_];
+        if (threadIdx.x < 256u)                    // the dense aligned copy of the feedback matrix: [32 columns][8 actions]
+            reinterpret_cast<float *>(smem + PL::OFF_WD)[threadIdx.x] = q.pol->Wt[threadIdx.x >> 3][threadIdx.x & 7u];
+    }
+    if (threadIdx.x < 16u) reinterpret_cast<uint32_t *>(smem + PL::OFF_SYNC)[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = (blockIdx.x + q.block0) * 256u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4u) pg_pair_producer<false, true, QA>(q, base, smem, wave - 4u, threadIdx.x & 63u);
+    else pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);
 }
 
 template <class E, class = void> struct pair_rollout : std::false_type {};

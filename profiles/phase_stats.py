@@ -19,7 +19,8 @@ def main():
     rec = json.loads([l for l in open(bench).read().splitlines() if l.startswith("{")][-1])
     kernel = rec["roofline"]["kernel"].replace(",", ", ")          # bench names it without blanks, the trace with
     phases = rec["rank_times"]["phases"]
-    rows = [r for r in csv.DictReader(open(trace)) if kernel.replace(" ", "") in r["Kernel_Name"].replace(" ", "").replace("nig::", "")]
+    want_name = kernel.replace(" ", "").rstrip(">")            # (the trace spells out defaulted template arguments: match the prefix)
+    rows = [r for r in csv.DictReader(open(trace)) if want_name in r["Kernel_Name"].replace(" ", "").replace("nig::", "")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     want = sum(p["launches"] for p in phases)
     out = [("phase", "kernel", "calls", "avg_us", "median_us", "min_us", "max_us", "first_start_ns", "span_ms")]

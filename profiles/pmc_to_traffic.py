@@ -65,7 +65,7 @@ def main():
     outputs = args[args.index("--outputs") + 1] if "--outputs" in args else "full"
     if env == "mixed":
         outputs = args[args.index("--mixed-outputs") + 1] if "--mixed-outputs" in args else "full"
-    want = ROLLOUT_RX if mode == "rollout" else "step_kernel"
+    want = ("mixed_rollout_kernel" if env == "mixed" else ROLLOUT_RX) if mode == "rollout" else "step_kernel"
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     try:
         allt = json.load(open(tpath))

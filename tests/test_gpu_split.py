@@ -184,11 +184,11 @@ def test_step_api_helper_waves_equal_the_plain_step_kernel(ni, name, B):
     assert float(a[-1][0].sum()) > B               # every lane finished several episodes
 
 
-def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5):
+def _run_policy(ni, split, policy, B, chunks, stream, max_steps, seed=5, name=NAME):
     """Closed-loop rollouts (nig_rollout_policy) through one handle; returns every observable as CPU tensors."""
     if split is not None:                      # None: keep the knob the caller set
         ni.tune(split_blocks=256 if split else 0)
-    env = ni.make_batched(NAME, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
+    env = ni.make_batched(name, B, seed=seed, autoreset=True, tally=True, max_episode_steps=max_steps)
     env.set_policy(policy)
     env.reset()
     got = []
@@ -236,6 +236,30 @@ def test_split_policy_form_with_a_ragged_tail_and_in_rounds(ni, B, split_blocks)
         kw = dict(policy=policy, B=B, chunks=[7, 6], stream="transitions", max_steps=9)
         ni.tune(split_blocks=split_blocks)
         a = _run_policy(ni, None, **kw)
+        b = _run_policy(ni, False, **kw)
+        _same(a, b)
+
+
+@pytest.mark.parametrize("stream", ["none", "rows", "transitions"])
+@pytest.mark.parametrize("which", ["expert", "medium", "random", "mpc", "constant", "uniform", "pid"])
+def test_powergrid_paired_closed_loop_equals_one_wave_form(ni, which, stream):
+    """Round 4: nig_rollout_policy for PowerGrid batches of at most one 256-lane block per compute unit runs the PAIRED
+    form (csrc/nig_pg_lds.hpp rollout_pg_pair_policy_kernel: the producer wave also draws the policy's own random numbers,
+    the stepping wave evaluates the feedback law on its LDS image) -- every affine policy kind (get_dataset's behaviour
+    laws power_grid.py:216-233 incl. the epsilon-mix with a uniform action, "MPC", constant, uniform random), with and
+    without the transition stream, whole blocks + a ragged last block, three launches chained -- bit-identical to
+    rollout_policy_kernel in rewards, flags, observations acted on, actions, final state, counters, returns, tallies.
+    A PID policy keeps the one-wave kernel (its memory lives in registers): same call, same results."""
+    S, A = 32, 8
+    name = "PowerGrid-v0"
+    if which in ("expert", "medium", "random"):
+        policy = ni.behaviour_policy(name, which)
+    else:
+        policy = {"pid": lambda: ni.pid_agent(S, A), "mpc": lambda: ni.mpc_agent(S, A), "constant": lambda: ni.constant_agent(S, A),
+                  "uniform": lambda: ni.random_agent(S, A)}[which]()
+    for B in (1024, 512 + 77):
+        kw = dict(policy=policy, B=B, chunks=[9, 1, 14], stream=stream, max_steps=11, name=name)
+        a = _run_policy(ni, True, **kw)
         b = _run_policy(ni, False, **kw)
         _same(a, b)
 
