@@ -723,7 +723,9 @@ def main():
     powergrid = None
     if key == "cr" and args.mode == "rollout" and not args.no_powergrid:
         Bp = BASELINE_BATCH["pg"]
-        w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, min(args.ring, 16), args.outputs, args.traj)
+        # action ring of 34 slots = 285 MB: larger than the 256 MB Infinity Cache, so every action read of this record comes
+        # from HBM and all 168 B per env-step are HBM-side bytes (roofline_of; a 16-slot ring sat inside the cache)
+        w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, 34, args.outputs, args.traj)
         K3 = max(2, min(K, 8))
         pg_times = {}
         pw, pd = timed(torch, dist, world, comm_dev, w3, K3, 2, args.settle, stats=pg_times)

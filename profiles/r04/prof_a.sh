@@ -9,7 +9,7 @@ export TMPDIR=/tmp NIG_PROFILE_ROUND=r04
 python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
 export NIG_NO_AUTOBUILD=1
 R=profiles/r04
-run() { echo "== $*" ; timeout -k 10 200 "$@"; echo "   rc=$?"; }
+run() { echo "== $*" >&2; timeout -k 10 200 "$@"; echo "   rc=$?" >&2; }
 run bash profiles/run_profile.sh r04_cr65536_driver --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_prof_driver.log 2>&1 \
   && cp gpurun_out/prof_r04_cr65536_driver/bench.json $R/cr65536_driver_bench.json \
   && cp gpurun_out/prof_r04_cr65536_driver/r04_cr65536_driver_kernel_stats.csv $R/cr65536_driver_all_launches_kernel_stats.csv \
