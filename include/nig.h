@@ -160,6 +160,8 @@ const char *nig_last_error(void);
 enum { NIG_TUNE_SPLIT_BLOCKS = 0, NIG_TUNE_WIDE_MIN_BLOCKS = 1, NIG_TUNE_DIAG_RING_FAULT = 2 };
 int nig_tune(int32_t key, int64_t value);
 int64_t nig_tune_get(int32_t key);
+/* the value in effect for THIS handle (its own device's default unless an explicit setting exists); -1: NULL handle / unknown key */
+int64_t nig_handle_tune_get(const nig_handle *h, int32_t key);
 
 /* utils.make registry lookup (utils.py:26-35): name -> id, or -1 */
 int nig_env_id(const char *name);

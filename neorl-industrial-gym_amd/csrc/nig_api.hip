@@ -332,6 +332,12 @@ int64_t nig_tune_get(int32_t key)
     return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::split_blocks_for(cus) : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::wide_min_blocks_for(cus) : -1;
 }
 
+int64_t nig_handle_tune_get(const nig_handle *h, int32_t key)
+{
+    if (!h) return -1;
+    return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::split_blocks_for(h->cus) : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::wide_min_blocks_for(h->cus) : -1;
+}
+
 int nig_env_id(const char *name)
 {
     if (!name) return -1;

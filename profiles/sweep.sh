@@ -4,7 +4,7 @@
 tag=$1; out=gpurun_out/sweep_$tag.jsonl; mkdir -p gpurun_out; : > $out
 python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
 export NIG_NO_AUTOBUILD=1
-run() { echo "# $*" >> $out; timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity --no-powergrid --no-mixed --no-brackets "$@" 2>/dev/null >> $out; }
+run() { echo "# $*" >> $out; timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity --no-powergrid --no-mixed --no-brackets --no-single-env "$@" 2>/dev/null >> $out; }
 run --env cr --batch 65536 --outputs full --steps 60 --warmup 10
 run --env cr --batch 65536 --outputs min --no-step-api --steps 60 --warmup 10
 run --env cr --batch 65536 --outputs none --no-step-api --steps 60 --warmup 10
@@ -33,6 +33,6 @@ for l in open(sys.argv[1]):
     r = d.get("roofline") or {}
     s = d.get("step_api") or {}
     print("  value %.3e  ms/step %.4f  frac %s  launch_us %s | step_api %s launch_us %s frac %s" % (
-        d["value"], d["ms_per_step"], r.get("frac"), r.get("launch_us"),
+        d["value"], d["ms_per_step"], "%.3f (alg %.3f)" % (r.get("frac", 0), r.get("frac_algorithmic", r.get("frac", 0))), r.get("launch_us"),
         s.get("value"), s.get("launch_us"), s.get("frac_of_hbm_peak")))
 PY
