@@ -330,6 +330,15 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < 7; ++i) n[16 + i] = 2.0f * n[16 + i];        // :144
     }
+    // the same scaling for normals somebody else generated (the paired form's producer wave): z = the 23 raw normals of
+    // gen_normals<KS>(k, STREAM_STEP) in order (a 24th padding entry is ignored)
+    __device__ static void scale_step_normals(const float (&z)[24], float (&n)[KS])
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { n[i] = 0.005f * z[i]; n[8 + i] = z[8 + i]; }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) n[16 + i] = 2.0f * z[16 + i];
+    }
     __device__ static void draw_step(const RngKey &k, double (&n)[KS])
     {
         float z[KS];

@@ -75,6 +75,9 @@ struct StepArgs {
 constexpr uint32_t HF_MAY_HOLD_DONE = 0x10000u;
 // test-only (NIG_RING_SPIN_LIMIT builds, nig_ring.hpp): producing roles stop posting after 7 steps
 constexpr uint32_t HF_DIAG_RING_FAULT = 0x20000u;
+}  // namespace nig
+#include "nig_ring.hpp"        // LDS ring counters of the cooperating-wave kernels (used from rollout_body's RING form on)
+namespace nig {
 
 // IndustrialEnv.step for one lane, entirely in registers (base.py:157-213): action clip, constraint
 // check on the pre-state and dynamics, then post_core = reward / penalties / termination on the
@@ -663,11 +666,19 @@ struct RolloutLds {
 // noise is loaded as the float64 values the dynamics' parity branch takes, and a finishing lane restarts from
 // Env::init(recorded draws) -- _get_initial_state itself, per lane, in place of the cooperative / compacted schemes
 // (whose work items contain the generator).  Every other instruction of the step is the timed kernel's.
-template <class Env, int OUT, bool PAIRED, bool FULL, bool NOFREEZE = false, int BLK = 256, bool NOISE = false>
-__device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem)
+// RING (the paired form of an env with many draws per step, PowerGrid: rollout_pg_pair_kernel<.., REG>): the step's normals
+// come from a PRODUCER wave through an LDS ring (nig_pg_lds.hpp pg_pair_producer: [generator block][lane] float4 slots of raw
+// normals, two slots, counters at ring_sync) instead of this wave's own generator; the caller has staged the generator's table
+// and passed the block barrier.  State, counters and tallies stay in REGISTERS: at the two waves per SIMD of that form the
+// register file has room for them, and the step is then one dependent chain of arithmetic instead of a chain of LDS round trips.
+template <class Env, int OUT, bool PAIRED, bool FULL, bool NOFREEZE = false, int BLK = 256, bool NOISE = false, bool RING = false>
+__device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_t base, unsigned char *smem,
+                                             const v4f *ring_slots = nullptr, lds_u32_t *ring_sync = nullptr)
 {
     static_assert(!NOFREEZE || FULL, "NOFREEZE is a property of whole-block launches");
     static_assert(!NOISE || !PAIRED, "injected draws: nothing to share between the steps of a pair");
+    static_assert(!RING || (!NOISE && !PAIRED && FULL && NOFREEZE && Env::KS > 4 && std::is_same<typename Env::fast_noise_t, float>::value),
+                  "ring-fed form: whole blocks of an env with float32 step noise");
     static_assert(BLK == 256 || (Env::COOP_RESET && !Env::COMPACT_RESET), "wide blocks: no block barrier inside the loop");
     constexpr int BLOCK = BLK;                   // shadows the file-wide constant
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
@@ -695,8 +706,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
     unsigned short *const s_list = reinterpret_cast<unsigned short *>(smem + Lds::OFF_LIST);
     int *const s_cnt = reinterpret_cast<int *>(smem + Lds::OFF_CNT);
     v4f *const s_tr = reinterpret_cast<v4f *>(smem + Lds::OFF_TR);               // per wave: [16 S] transpose image of the row-major observation rows (64 x S floats)
-    for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit[i_] = NIG_PROBIT[i_];
-    __syncthreads();                       // every thread of the block passes here before any early exit
+    if constexpr (!RING) {                 // (ring-fed form: the kernel staged the table with all its waves)
+        for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit[i_] = NIG_PROBIT[i_];
+        __syncthreads();                   // every thread of the block passes here before any early exit
+    }
+    [[maybe_unused]] uint32_t ring_seen = 0u;
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x;
     const bool in_range = FULL ? true : (base + tid < p.B);
@@ -778,6 +792,17 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &q, const uint32_
 #pragma unroll
                 for (int k = 0; k < KS; ++k) nz[k] = in_range ? (nzr + (size_t)k * p.ld_noise)[tid] : 0.0;
             }
+        } else if constexpr (RING) {
+            // the producer's slot of this step: raw normals, [generator block][lane]; scaled here exactly as Env::draw_step does
+            const int itl = it - q.it0;
+            if (ring_seen < (uint32_t)itl + 1u) ring_seen = split_wait(ring_sync + 0, (uint32_t)itl + 1u);
+            constexpr int NB = (KS + 3) / 4;
+            const v4f *slot = ring_slots + (itl & 1) * (NB * 64) + (tid & 63u);
+            float z[4 * NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const v4f w = slot[64 * j]; z[4 * j] = w.x; z[4 * j + 1] = w.y; z[4 * j + 2] = w.z; z[4 * j + 3] = w.w; }
+            split_post(ring_sync + 1, (uint32_t)itl + 1u, tid & 63u);     // (DS order: the reads above execute before this write)
+            Env::scale_step_normals(z, nz);
         } else if constexpr (KS > 0 && !SHARE) draw_one<Env>(key, nz);
         step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
         const int step = step_pre + 1;
@@ -1023,7 +1048,6 @@ template <class Env, class PV> __device__ __forceinline__ void policy_affine(con
 template <class Env, class PV> __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A]);
 
 }  // namespace nig
-#include "nig_ring.hpp"
 #include "nig_pg_lds.hpp"
 namespace nig {
 template <class Env, int OUT, int BLK, bool NOISE = false>
@@ -1862,10 +1886,19 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
                     if constexpr (NOISE) hipLaunchKernelGGL((rollout_pg_pair_kernel<3, true>), dim3(n_full), dim3(512), 0, st, r);
                     else
                     switch (out_mode) {
-                    case 0: hipLaunchKernelGGL((rollout_pg_pair_kernel<0>), dim3(n_full), dim3(512), 0, st, r); break;
-                    case 1: hipLaunchKernelGGL((rollout_pg_pair_kernel<1>), dim3(n_full), dim3(512), 0, st, r); break;
-                    case 2: hipLaunchKernelGGL((rollout_pg_pair_kernel<2>), dim3(n_full), dim3(512), 0, st, r); break;
-                    default: hipLaunchKernelGGL((rollout_pg_pair_kernel<3>), dim3(n_full), dim3(512), 0, st, r); break;
+#ifdef NIG_DIAG_PG_PAIR_LDS            // (diagnostic builds only: round 3's LDS-resident stepping waves, for same-box A/Bs)
+#define NIG_PG_PAIR_REG false
+#else
+#define NIG_PG_PAIR_REG true
+#endif
+                    case 0: hipLaunchKernelGGL((rollout_pg_pair_kernel<0, false, NIG_PG_PAIR_REG>), dim3(n_full), dim3(512), 0, st, r); break;
+                    case 1: hipLaunchKernelGGL((rollout_pg_pair_kernel<1, false, NIG_PG_PAIR_REG>), dim3(n_full), dim3(512), 0, st, r); break;
+                    // (with an observation trajectory the LDS-resident stepping body stays: its state image IS the transposing
+                    // image of the row-major rows; the register body pays an extra LDS round trip for them -- same box, 65 536
+                    // lanes x 250 steps: reward + flags 665 -> 582 us, no outputs 643 -> 557 us with registers, but full outputs
+                    // 687 -> 774 us: profiles/r04/pg_pair_reg_ab.txt)
+                    case 2: hipLaunchKernelGGL((rollout_pg_pair_kernel<2, false, false>), dim3(n_full), dim3(512), 0, st, r); break;
+                    default: hipLaunchKernelGGL((rollout_pg_pair_kernel<3, false, false>), dim3(n_full), dim3(512), 0, st, r); break;
                     }
                     first = n_full;
                 }

@@ -118,10 +118,23 @@ template <class QA> __device__ __forceinline__ int arg_it0(const QA &q)
     if constexpr (std::is_same<QA, RolloutArgs>::value) return q.it0; else return 0;     // (closed-loop launches start at call step 0)
 }
 
-template <bool NOISE = false, bool POLICY = false, class QA = RolloutArgs>
+// The paired form with the stepping waves' state in REGISTERS (rollout_body's RING form; round 4): the LDS of a block = the
+// register-resident rollout's own layout (generator table, per-wave reset / transpose scratch), then the producers' ring.
+template <int OUT>
+struct PgPairRegLds {
+    static constexpr int K = 2;
+    static constexpr int NZ_V4 = 6 * 64, SLOT_V4 = NZ_V4;
+    static constexpr int OFF_POL = 0;                                  // (unused: open loop)
+    static constexpr int OFF_NZ = (RolloutLds<PowerGrid, OUT, 256>::BYTES + 15) / 16 * 16;
+    static constexpr int OFF_SYNC = OFF_NZ + 4 * K * SLOT_V4 * 16;
+    static constexpr int BYTES = OFF_SYNC + 4 * 16;
+    static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+};
+
+template <bool NOISE = false, bool POLICY = false, class QA = RolloutArgs, class LL = PgPairLdsT<NOISE, POLICY>>
 __device__ __forceinline__ void pg_pair_producer(const QA &q, const uint32_t base, unsigned char *smem, const unsigned wave, const unsigned lane)
 {
-    using L = PgPairLdsT<NOISE, POLICY>;
+    using L = LL;
     static_assert(!(NOISE && POLICY), "recorded draws exist for the open loop only");
     [[maybe_unused]] const nig_policy *const pol = reinterpret_cast<const nig_policy *>(smem + L::OFF_POL);
     const float4 *const s_probit = reinterpret_cast<const float4 *>(smem + PgLds<256>::OFF_PROBIT);
@@ -621,10 +634,16 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
 
 // The paired form's kernel: 256 lanes per block, 512 threads -- waves 0-3 step (pg_lds_rollout_body, PROD), waves 4-7
 // produce their normals (pg_pair_producer).  q.block0 counts 256-lane blocks.  One block per compute unit is resident.
-template <int OUT, bool NOISE = false>
+// REG (round 4, the default of the open loop): the stepping waves run the REGISTER-resident rollout body fed from the
+// producers' ring (rollout_body<PowerGrid, ..., RING>): at this form's two waves per SIMD a wave may hold 256 registers, and
+// with state, counters and tallies in registers a step is one chain of arithmetic -- the LDS-resident body (REG = false: what
+// round 3 ran here, and what the injected-draw variant still runs) walks its state image through ~50 dependent LDS round
+// trips per step, ~10 cycles per instruction on the stepping wave.
+template <int OUT, bool NOISE = false, bool REG = false>
 __global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutArgs q)
 {
-    using PL = PgPairLdsT<NOISE>;
+    using PL = std::conditional_t<REG, PgPairRegLds<OUT>, PgPairLdsT<NOISE>>;
+    static_assert(!(REG && NOISE), "recorded draws: the LDS-resident stepping body");
     __shared__ __attribute__((aligned(16))) unsigned char smem[PL::BYTES];
     float4 *const s_probit = reinterpret_cast<float4 *>(smem + PgLds<256>::OFF_PROBIT);
     for (int i_ = (int)threadIdx.x; i_ < 768; i_ += 512) s_probit[i_] = NIG_PROBIT[i_];
@@ -632,8 +651,13 @@ __global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutAr
     __syncthreads();
     const uint32_t base = (blockIdx.x + q.block0) * 256u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= 4u) pg_pair_producer<NOISE>(q, base, smem, wave - 4u, threadIdx.x & 63u);
-    else pg_lds_rollout_body<OUT, 256, true, NOISE>(q, base, smem);
+    if (wave >= 4u) pg_pair_producer<NOISE, false, RolloutArgs, PL>(q, base, smem, wave - 4u, threadIdx.x & 63u);
+    else if constexpr (REG) {
+        rollout_body<PowerGrid, OUT, false, true, true, 256, false, true>(
+            q, base, smem, reinterpret_cast<const v4f *>(smem + PL::OFF_NZ) + wave * (PL::K * PL::SLOT_V4),
+            (lds_u32_t *)(smem + PL::OFF_SYNC) + wave * 4);
+        NIG_RING_REPORT(q.s.ring_err, (lds_u32_t *)(smem + PL::OFF_SYNC) + wave * 4, threadIdx.x & 63u);
+    } else pg_lds_rollout_body<OUT, 256, true, NOISE>(q, base, smem);
 }
 
 // The paired form of the CLOSED loop (nig_rollout_policy, affine policies): as above, the producers also draw the policy's
