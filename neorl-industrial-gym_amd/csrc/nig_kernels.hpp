@@ -1047,6 +1047,72 @@ template <int A, class PV> __device__ __forceinline__ void policy_switches(const
 template <class Env, class PV> __device__ __forceinline__ void policy_affine(const PV *__restrict__ P, const float (&obs)[Env::S], float (&u)[Env::A]);
 template <class Env, class PV> __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A]);
 
+// Register copy of the policy fields a closed-loop form reads every step besides the feedback matrix (same field names as
+// nig_policy: policy_finish / policy_switches take either).  Read in place from LDS, every field was an exposed ds_read round
+// trip per step on the wave that evaluates the law.
+template <int A>
+struct PolicyHead {
+    int32_t kind; uint32_t colmask;
+    float b[A], sigma[A], half_range[A], setpoint[A], p_uniform, uniform_range, clip_lo, clip_hi, kp, ki, kd;
+    __device__ __forceinline__ void load(const nig_policy &P)
+    {
+        kind = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)P.kind);
+        colmask = __builtin_amdgcn_readfirstlane(P.colmask);
+#pragma unroll
+        for (int j = 0; j < A; ++j) { b[j] = P.b[j]; sigma[j] = P.sigma[j]; half_range[j] = P.half_range[j]; setpoint[j] = P.setpoint[j]; }
+        p_uniform = P.p_uniform; uniform_range = P.uniform_range; clip_lo = P.clip_lo; clip_hi = P.clip_hi;
+        kp = P.kp; ki = P.ki; kd = P.kd;
+    }
+};
+
+// policy_affine for envs whose feedback matrix does not fit registers (PowerGrid 32 x 8, RobotAssembly 24 x 7): u_j = b_j +
+// sum_k Wt[k][j] obs[k], ascending k, zero columns skipped -- the same operations on the same values as policy_affine -- with
+// the matrix read from a dense 16-byte-aligned LDS copy [S rounded up to 8][8 actions] EIGHT COLUMNS AHEAD: sixteen
+// ds_read_b128 in flight, one wait, then the columns' multiply-adds behind wave-uniform tests of the column mask.  (Read
+// column by column inside those tests, every active column cost two exposed LDS round trips: 34 per step for PowerGrid's
+// "expert" law -- +1.9 us per step, which made the paired closed loop no faster than the one-wave kernel.)
+// (COLS: columns read ahead per batch -- eight where the wave has registers to spare, four on RobotAssembly's integrator)
+template <class Env, int COLS = 8, class PV = PolicyHead<Env::A>>
+__device__ __forceinline__ void policy_affine_dense(const PV &H, const v4f *__restrict__ wd, const float (&obs)[Env::S], float (&u)[Env::A])
+{
+    constexpr int S = Env::S, A = Env::A;
+    static_assert(A <= 8, "dense copy holds eight actions per column");
+#pragma unroll
+    for (int j = 0; j < A; ++j) u[j] = H.b[j];
+    const uint32_t cm = H.colmask;
+#pragma unroll
+    for (int q8 = 0; COLS * q8 < S; ++q8) {
+        if ((cm >> (COLS * q8)) & ((1u << COLS) - 1u)) {      // wave-uniform: any column of this batch in use?
+            v4f c[COLS][2];
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                if (COLS * q8 + k < S) { c[k][0] = wd[(COLS * q8 + k) * 2]; c[k][1] = wd[(COLS * q8 + k) * 2 + 1]; }
+            }
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                if (COLS * q8 + k < S) {
+                    if (cm & (1u << (COLS * q8 + k))) {   // wave-uniform: whole zero columns are skipped (as policy_affine)
+                        const float o = obs[COLS * q8 + k];
+                        const float w[8] = {c[k][0].x, c[k][0].y, c[k][0].z, c[k][0].w, c[k][1].x, c[k][1].y, c[k][1].z, c[k][1].w};
+#pragma unroll
+                        for (int j = 0; j < A; ++j) u[j] = u[j] + w[j] * o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fills the dense copy (every thread of the block calls it before the block barrier): wd[k][j] = Wt[k][j], j < 8
+template <class Env>
+__device__ __forceinline__ void policy_stage_dense(const nig_policy *gpol, float *wd, unsigned tid, unsigned nthreads)
+{
+    constexpr int SP = (Env::S + 7) / 8 * 8;
+    for (unsigned i = tid; i < (unsigned)SP * 8u; i += nthreads)
+        wd[i] = ((int)(i >> 3) < Env::S && (int)(i & 7u) < Env::A) ? gpol->Wt[i >> 3][i & 7u] : 0.0f;
+}
+
+
 }  // namespace nig
 #include "nig_pg_lds.hpp"
 namespace nig {
@@ -1191,12 +1257,13 @@ __device__ __forceinline__ void policy_affine(const PV *__restrict__ P, const fl
     }
 }
 
+// (the switches and the clip bounds handed in: a caller that keeps them in registers across its loop spares the wave that
+// evaluates the law ~16 LDS reads and a round trip per step)
 template <class Env, class PV>
-__device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A])
+__device__ __forceinline__ void policy_finish_sw(const PV *__restrict__ P, bool any_sigma, bool any_half, bool mix, float lo, float hi,
+                                                 const PolicyDraws<Env::A> &d, float (&u)[Env::A])
 {
     constexpr int A = Env::A;
-    bool any_sigma, any_half, mix;
-    policy_switches<A>(P, any_sigma, any_half, mix);
     if (any_sigma) {
 #pragma unroll
         for (int j = 0; j < A; ++j) u[j] = u[j] + P->sigma[j] * d.z[j];
@@ -1210,7 +1277,6 @@ __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const Po
 #pragma unroll
         for (int j = 0; j < A; ++j) u[j] = rnd ? d.ra[j] : u[j];
     }
-    const float lo = P->clip_lo, hi = P->clip_hi;
 #pragma unroll
     for (int j = 0; j < A; ++j) {                  // np.clip == minimum(maximum(x, lo), hi)
         float x = u[j];
@@ -1218,6 +1284,14 @@ __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const Po
         x = (x > hi) ? hi : x;
         u[j] = x;
     }
+}
+
+template <class Env, class PV>
+__device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A])
+{
+    bool any_sigma, any_half, mix;
+    policy_switches<Env::A>(P, any_sigma, any_half, mix);
+    policy_finish_sw<Env>(P, any_sigma, any_half, mix, P->clip_lo, P->clip_hi, d, u);
 }
 
 template <class Env, class PV>
@@ -1950,16 +2024,19 @@ static void launch_rollout_env(int out_mode, const RolloutArgs &q, uint32_t t0, 
 template <class Env>
 static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
 {
-    if constexpr (split_rollout<Env>::value && Env::SHARED_STEP_BLOCK) {     // (the closed-loop form exists for ChemicalReactor's shape)
+    if constexpr (split_rollout<Env>::value && (Env::SHARED_STEP_BLOCK || Env::KS == 0)) {
         // Producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp) for the batch's whole 256-lane blocks --
-        // up to one block per CU, and larger batches in rounds under the rule of the open-loop rollout (the last round at
-        // least 3/4 full) -- and the one-wave kernel for a ragged last block.  (Round 2 sent a batch with a ragged tail,
-        // or of more than one round, to the one-wave kernel whole.)
+        // up to one block per CU, and (ChemicalReactor) larger batches in rounds under the rule of the open-loop rollout (the last
+        // round at least 3/4 full) -- and the one-wave kernel for a ragged last block.  RobotAssembly (round 4: S = 24, the
+        // form's BIG layout): a single round only, as in the open loop, and not when the caller wants the observations of the
+        // transition stream (its I -> C slots carry no observation rows).
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
         const unsigned n_full = q.s.B / BLOCK, per_round = q.s.split_blocks;
         const unsigned last_round = per_round ? n_full % per_round : 0u;
-        const bool even_rounds = per_round != 0 && (n_full <= per_round || last_round == 0 || 4u * last_round >= 3u * per_round);
-        if (plain && n_full > 0 && even_rounds) {
+        constexpr bool big = SplitPolicyLds<Env, BLOCK / 64>::BIG;
+        const bool even_rounds = per_round != 0 && (n_full <= per_round ||
+                                                    (!big && split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
+        if (plain && n_full > 0 && even_rounds && !(big && q.obs_out != nullptr)) {
             PolicyArgs r = q;
             r.block0 = 0;
             hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(n_full), dim3(192 * (BLOCK / 64)), 0, st, r);

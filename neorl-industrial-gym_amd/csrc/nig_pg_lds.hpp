@@ -71,48 +71,6 @@ struct PgPairLdsT {
 using PgPairLds = PgPairLdsT<false>;
 
 // producer wave `wave` (0-3) of the block: lanes base + 64 wave .. + 63, local steps [0, n)
-// Register copy of the policy fields the closed loop reads every step besides the feedback matrix (same field names as
-// nig_policy: policy_finish takes either).  Read in place from LDS, every field was an exposed ds_read round trip per step.
-struct PgPolicyHead {
-    uint32_t colmask;
-    float b[8], sigma[8], half_range[8], p_uniform, uniform_range, clip_lo, clip_hi;
-    __device__ __forceinline__ void load(const nig_policy &P)
-    {
-        colmask = __builtin_amdgcn_readfirstlane(P.colmask);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { b[j] = P.b[j]; sigma[j] = P.sigma[j]; half_range[j] = P.half_range[j]; }
-        p_uniform = P.p_uniform; uniform_range = P.uniform_range; clip_lo = P.clip_lo; clip_hi = P.clip_hi;
-    }
-};
-
-// policy_affine for PowerGrid's closed loop: u_j = b_j + sum_k Wt[k][j] obs[k], ascending k, zero columns skipped -- the same
-// operations on the same values as policy_affine (nig_kernels.hpp), with the matrix read from the dense LDS copy EIGHT
-// COLUMNS AHEAD: sixteen ds_read_b128 in flight, one wait, then the columns' multiply-adds behind wave-uniform tests of the
-// column mask.  (Read column by column inside those tests, every active column cost two exposed LDS round trips: 34 per step
-// for the "expert" law's 17 columns -- +1.9 us per step, which made the paired closed loop no faster than the one-wave kernel.)
-__device__ __forceinline__ void pg_policy_affine(const PgPolicyHead &H, const v4f *__restrict__ wd, const float (&obs)[32], float (&u)[8])
-{
-#pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = H.b[j];
-    const uint32_t cm = H.colmask;
-#pragma unroll
-    for (int q8 = 0; q8 < 4; ++q8) {
-        if ((cm >> (8 * q8)) & 0xFFu) {            // wave-uniform: any column of this quarter in use?
-            v4f c[8][2];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { c[k][0] = wd[(8 * q8 + k) * 2]; c[k][1] = wd[(8 * q8 + k) * 2 + 1]; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (cm & (1u << (8 * q8 + k))) {   // wave-uniform: whole zero columns are skipped (as policy_affine)
-                    const float o = obs[8 * q8 + k];
-                    u[0] = u[0] + c[k][0].x * o; u[1] = u[1] + c[k][0].y * o; u[2] = u[2] + c[k][0].z * o; u[3] = u[3] + c[k][0].w * o;
-                    u[4] = u[4] + c[k][1].x * o; u[5] = u[5] + c[k][1].y * o; u[6] = u[6] + c[k][1].z * o; u[7] = u[7] + c[k][1].w * o;
-                }
-            }
-        }
-    }
-}
-
 template <class QA> __device__ __forceinline__ int arg_it0(const QA &q)
 {
     if constexpr (std::is_same<QA, RolloutArgs>::value) return q.it0; else return 0;     // (closed-loop launches start at call step 0)
@@ -275,7 +233,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
     [[maybe_unused]] float *act_row = nullptr;     // POLICY: the policy's action rows [n_steps][A][ld] (optional)
     if constexpr (POLICY) { if (q.act_out) act_row = q.act_out + base; }
     [[maybe_unused]] bool any_sigma = false, any_half = false, mix = false;
-    [[maybe_unused]] PgPolicyHead head;
+    [[maybe_unused]] PolicyHead<A> head;
     [[maybe_unused]] const v4f *const wd = reinterpret_cast<const v4f *>(smem + PgPairLds::OFF_WD);
     if constexpr (POLICY) { policy_switches<A>(pol, any_sigma, any_half, mix); head.load(*pol); }
     const unsigned rd = (lane & 7u) * 8u + (lane >> 3);             // transposed read: image float4 64 j + rd = row-major float4 64 j + lane
@@ -299,7 +257,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, tv[j]);
                 obs_row += q.obs_step_stride;
             }
-            pg_policy_affine(head, wd, obs, a);
+            policy_affine_dense<Env>(head, wd, obs, a);
             if (nz_seen < (uint32_t)itl0 + 1u) nz_seen = split_wait(nz_sync + 0, (uint32_t)itl0 + 1u);
             const float *dr = reinterpret_cast<const float *>(nz_ring + (itl0 & (PgPairLds::K - 1)) * PgPairLds::SLOT_V4 + PgPairLds::NZ_V4) + lane;
             PolicyDraws<A> d;

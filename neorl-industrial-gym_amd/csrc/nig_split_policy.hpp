@@ -18,13 +18,19 @@ namespace nig {
 
 template <class Env, int NP>
 struct SplitPolicyLds {
-    static constexpr int K = 3;                                        // ring slots
+    // BIG (S > 16: RobotAssembly, round 4): two ring slots instead of three, no observation rows in the I -> C slot (a launch
+    // that wants the transition stream's observations runs the one-wave kernel), and the feedback matrix as a dense LDS copy
+    // (policy_affine_dense) instead of registers -- what makes four triples of a 24-value state fit one CU's 160 KiB.
+    static constexpr bool BIG = Env::S > 16;
+    static constexpr int K = BIG ? 2 : 3;                              // ring slots
     static constexpr int HI_ROWS = Env::KS + 3 * Env::A + 1;           // noise, z, h, ra, wmix
     static constexpr int HI_SLOT = HI_ROWS * 64;                       // floats
-    static constexpr int IH_SLOT = (2 * Env::S + 1 + Env::A) * 64;     // [64][S] observation acted on, [64][S] post-dynamics state, violation words, [A][64] action
+    static constexpr int OBS_ROWS = BIG ? 0 : Env::S;                  // [64][S] observation acted on (for the transition stream)
+    static constexpr int IH_SLOT = (OBS_ROWS + Env::S + 1 + Env::A) * 64;   // observation, [64][S] post-dynamics state, violation words, [A][64] action
     static constexpr int OFF_PROBIT = 0;
     static constexpr int OFF_POL = 768 * 16;
-    static constexpr int OFF_IMG = OFF_POL + (int)((sizeof(nig_policy) + 15) / 16 * 16);
+    static constexpr int OFF_WD = OFF_POL + (int)((sizeof(nig_policy) + 15) / 16 * 16);      // BIG: dense [S rounded up to 8][8] feedback matrix
+    static constexpr int OFF_IMG = OFF_WD + (BIG ? (Env::S + 7) / 8 * 8 * 8 * 4 : 0);
     static constexpr int OFF_WLIST = OFF_IMG + NP * Env::RESET_ROWS * 64 * 4;
     static constexpr int OFF_SYNC = OFF_WLIST + NP * 64;
     static constexpr int OFF_HI = OFF_SYNC + NP * 16;
@@ -37,9 +43,13 @@ template <class Env, int NP>
 __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS;
-    static_assert(Env::SHARED_STEP_BLOCK && Env::COOP_RESET && !Env::CUSTOM_STEP && KS == 2 && S % 4 == 0, "written for ChemicalReactor's shape");
+    static_assert(Env::COOP_RESET && !Env::CUSTOM_STEP && S % 4 == 0 && ((Env::SHARED_STEP_BLOCK && KS == 2) || KS == 0),
+                  "three-wave closed loop: cooperative reset, S a multiple of 4, ChemicalReactor's step noise or none");
     using Lds = SplitPolicyLds<Env, NP>;
     constexpr int K = Lds::K;
+    constexpr bool BIG = Lds::BIG;
+    constexpr int KN = KS > 0 ? KS : 1;
+    constexpr int OBS = Lds::OBS_ROWS;             // rows of the I -> C slot before the post-dynamics state
     constexpr int THREADS = 192 * NP;
     constexpr int ROW_Z = KS, ROW_H = KS + A, ROW_RA = KS + 2 * A, ROW_MIX = KS + 3 * A;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Lds::BYTES];
@@ -56,6 +66,7 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
         const uint32_t *src = reinterpret_cast<const uint32_t *>(q.pol);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem + Lds::OFF_POL);
         for (unsigned i_ = tid; i_ < sizeof(nig_policy) / 4; i_ += THREADS) dst[i_] = src[i_];
+        if constexpr (BIG) policy_stage_dense<Env>(q.pol, reinterpret_cast<float *>(smem + Lds::OFF_WD), tid, THREADS);
     }
     if (tid < NP * 4) reinterpret_cast<uint32_t *>(smem + Lds::OFF_SYNC)[tid] = 0u;
     __syncthreads();
@@ -75,10 +86,12 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
         uint32_t freed = 0u;
         for (int j = 0; j < n; ++j) {
             const RngKey key = make_key(gi, t_base + (uint32_t)j + 1u, p.seed_lo, p.seed_hi, s_probit);
-            const bool second = (key.t & 1u) == 0u;                  // launch counters 2k-1, 2k share one Philox block (draw_step)
-            if (!second || j == 0) blk = Env::step_block(key);
-            typename Env::fast_noise_t nz[KS];
-            Env::step_noise(second ? blk.z : blk.x, second ? blk.w : blk.y, s_probit, nz);
+            typename Env::fast_noise_t nz[KN];
+            if constexpr (KS > 0) {
+                const bool second = (key.t & 1u) == 0u;              // launch counters 2k-1, 2k share one Philox block (draw_step)
+                if (!second || j == 0) blk = pair_block<Env>(key);
+                pair_noise<Env>(second ? blk.z : blk.x, second ? blk.w : blk.y, s_probit, nz);
+            }
             PolicyDraws<A> d;
             policy_draws<Env>(pol, key, d);
             if (freed + (uint32_t)K < (uint32_t)j + 1u) freed = split_wait(sync + 2, (uint32_t)(j + 1 - K));
@@ -120,8 +133,20 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
             integ[j] = pid_mem ? (q.pid + base + (size_t)j * p.ld)[lane] : 0.0f;
             eprev[j] = pid_mem ? (q.pid + base + (size_t)(A + j) * p.ld)[lane] : 0.0f;
         }
-        PolicyRegs<Env> pr;                        // the feedback law's coefficients in registers (see PolicyRegs)
-        pr.load(*pol);
+        // the law's coefficients in registers (PolicyRegs); BIG: only offsets and column mask -- RobotAssembly's integrator has
+        // no registers to spare (153 of 168 in the open loop), the matrix comes from the dense LDS copy four columns ahead and
+        // the rarely used per-action fields (noise scales, PID set-points, clip) are read in place
+        struct SmallHead { uint32_t colmask; float b[A], clip_lo, clip_hi; };
+        std::conditional_t<BIG, SmallHead, PolicyRegs<Env>> pr;
+        if constexpr (BIG) {
+            pr.colmask = __builtin_amdgcn_readfirstlane(pol->colmask);
+            pr.clip_lo = pol->clip_lo; pr.clip_hi = pol->clip_hi;
+#pragma unroll
+            for (int j = 0; j < A; ++j) pr.b[j] = pol->b[j];
+        } else {
+            pr.load(*pol);
+        }
+        [[maybe_unused]] const v4f *const wd = reinterpret_cast<const v4f *>(smem + Lds::OFF_WD);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_setprio(3);
         int slot = 0;
@@ -129,7 +154,8 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
         for (int i = 0; i < n; ++i) {
             if (seen < (uint32_t)i + 1u) seen = split_wait(sync + 0, (uint32_t)i + 1u);
             const float *hi = s_hi + slot * Lds::HI_SLOT;
-            double nz[KS];
+            double nz[KN];
+            nz[0] = 0.0;
 #pragma unroll
             for (int k = 0; k < KS; ++k) nz[k] = (double)hi[k * 64 + lane];
             PolicyDraws<A> d;
@@ -147,20 +173,38 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
                 d.wmix = hi[ROW_MIX * 64 + lane];
             }
             float a[A];
-            policy_apply<Env>(&pr, s, d, integ, eprev, a);
+            if constexpr (BIG) {                   // the same law, its matrix prefetched from the dense LDS copy
+                if (pol->kind == NIG_POLICY_PID) {   // baseline_agents.py:61-80 (policy_apply's branch)
+                    const float kp = pol->kp, ki = pol->ki, kd = pol->kd;
+#pragma unroll
+                    for (int j = 0; j < A; ++j) {
+                        const float e = pol->setpoint[j] - s[j];
+                        integ[j] = integ[j] + e;
+                        a[j] = (kp * e + ki * integ[j]) + kd * (e - eprev[j]);
+                        eprev[j] = e;
+                    }
+                } else {
+                    policy_affine_dense<Env, 4>(pr, wd, s, a);
+                }
+                policy_finish_sw<Env>(pol, any_sigma, any_half, mix, pr.clip_lo, pr.clip_hi, d, a);
+            } else {
+                policy_apply<Env>(&pr, s, d, integ, eprev, a);
+            }
             float *ih = s_ih + slot * Lds::IH_SLOT;
-            v4f *row = reinterpret_cast<v4f *>(ih) + lane * (S / 4);
+            if constexpr (OBS > 0) {
+                v4f *row = reinterpret_cast<v4f *>(ih) + lane * (S / 4);
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; row[k] = v; }
+                for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; row[k] = v; }
+            }
 #pragma unroll
-            for (int k = 0; k < A; ++k) ih[(2 * S + 1 + k) * 64 + lane] = a[k];          // the policy's action, before the env's clip
+            for (int k = 0; k < A; ++k) ih[(OBS + S + 1 + k) * 64 + lane] = a[k];        // the policy's action, before the env's clip
             StepResult<Env> res;
             step_core<Env>(s, a, nz, step, p.max_steps, p.dt32, p.dt, p.cmask, nx, res);  // the reward part is dead here
             const bool done = res.terminated || res.truncated;
-            v4f *rown = reinterpret_cast<v4f *>(ih + S * 64) + lane * (S / 4);
+            v4f *rown = reinterpret_cast<v4f *>(ih + OBS * 64) + lane * (S / 4);
 #pragma unroll
             for (int k = 0; k < S / 4; ++k) { v4f v = {nx[4 * k], nx[4 * k + 1], nx[4 * k + 2], nx[4 * k + 3]}; rown[k] = v; }
-            reinterpret_cast<uint32_t *>(ih + 2 * S * 64)[lane] = res.viol_bits;
+            reinterpret_cast<uint32_t *>(ih + (OBS + S) * 64)[lane] = res.viol_bits;
             split_post(sync + 1, (uint32_t)i + 1u, lane);
             step = done ? 0 : step + 1;
             const unsigned long long m = __ballot(done);
@@ -197,23 +241,27 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
         if (seen < (uint32_t)i + 1u) seen = split_wait(sync + 1, (uint32_t)i + 1u);
         const float *ih = s_ih + cslot * Lds::IH_SLOT;
         float nx[S], a[A];
-        const v4f *rown = reinterpret_cast<const v4f *>(ih + S * 64) + lane * (S / 4);
+        const v4f *rown = reinterpret_cast<const v4f *>(ih + OBS * 64) + lane * (S / 4);
 #pragma unroll
         for (int k = 0; k < S / 4; ++k) { const v4f v = rown[k]; nx[4 * k] = v.x; nx[4 * k + 1] = v.y; nx[4 * k + 2] = v.z; nx[4 * k + 3] = v.w; }
-        const uint32_t vb = reinterpret_cast<const uint32_t *>(ih + 2 * S * 64)[lane];
+        const uint32_t vb = reinterpret_cast<const uint32_t *>(ih + (OBS + S) * 64)[lane];
 #pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = ih[(2 * S + 1 + k) * 64 + lane];
-        v4f tr[S / 4];
+        for (int k = 0; k < A; ++k) a[k] = ih[(OBS + S + 1 + k) * 64 + lane];
+        [[maybe_unused]] v4f tr[S / 4];
+        if constexpr (OBS > 0) {
         if (q.obs_out) {                           // the wave's 64 observation rows in lane-contiguous order
 #pragma unroll
             for (int k = 0; k < S / 4; ++k) tr[k] = reinterpret_cast<const v4f *>(ih)[lane + 64u * k];
         }
+        }
         split_post(sync + 2, (uint32_t)i + 1u, lane);
         const uint32_t orow = (uint32_t)i * q.out_stride;
+        if constexpr (OBS > 0) {
         if (q.obs_out) {
             v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)i * q.obs_step_stride + (size_t)base * S);
 #pragma unroll
             for (int k = 0; k < S / 4; ++k) stream_store(oo + lane + 64u * k, tr[k]);
+        }
         }
         if (q.act_out) {
             float *ao = q.act_out + (size_t)i * q.act_step_stride + base;

@@ -264,6 +264,28 @@ def test_powergrid_paired_closed_loop_equals_one_wave_form(ni, which, stream):
         _same(a, b)
 
 
+@pytest.mark.parametrize("stream", ["none", "rows", "transitions"])
+@pytest.mark.parametrize("which", ["expert", "medium", "random", "mpc", "constant", "uniform", "pid"])
+def test_robot_assembly_three_wave_closed_loop_equals_one_wave_form(ni, which, stream):
+    """Round 4: nig_rollout_policy for RobotAssembly batches of at most one 256-lane block per compute unit runs the three-wave
+    closed-loop form in its BIG layout (csrc/nig_split_policy.hpp: two ring slots, no observation rows in the I -> C slot, the
+    feedback matrix prefetched from a dense LDS copy) -- get_dataset's behaviour laws (robot_assembly.py:266-290: feedback +
+    uniform perturbations + epsilon-mix, clip to +-2), "MPC", constant, uniform random and PID (memory across launches) --
+    bit-identical to rollout_policy_kernel in rewards, flags, actions, final state, counters, returns, tallies, PID memory;
+    with the transition stream's observations requested the call stays on the one-wave kernel (same results by construction)."""
+    S, A = 24, 7
+    if which in ("expert", "medium", "random"):
+        policy = ni.behaviour_policy(RA, which)
+    else:
+        policy = {"pid": lambda: ni.pid_agent(S, A), "mpc": lambda: ni.mpc_agent(S, A), "constant": lambda: ni.constant_agent(S, A),
+                  "uniform": lambda: ni.random_agent(S, A)}[which]()
+    for B in (1024, 256 + 50):
+        kw = dict(policy=policy, B=B, chunks=[9, 1, 14], stream=stream, max_steps=11, name=RA)
+        a = _run_policy(ni, True, **kw)
+        b = _run_policy(ni, False, **kw)
+        _same(a, b)
+
+
 @pytest.mark.parametrize("max_steps", [1, 2, 3])
 def test_split_form_resets_every_step(ni, max_steps):
     """Episodes of one to three steps: every lane (or half / a third of them) is renewed by the cooperative reset
