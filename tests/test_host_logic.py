@@ -392,6 +392,75 @@ def test_bench_timed_interval_holds_no_collective():
     assert stats["wall_s_per_rank"] == [wall, wall]
 
 
+def test_bench_hbm_side_fraction_counts_only_what_the_cache_cannot_serve():
+    """roofline.frac (round 4): a byte stream counts when its footprint exceeds the 256 MB Infinity Cache.  Headline shape:
+    917 MB of per-step outputs count (56 of the 68 B), the 50 MB action ring does not; rings larger than the cache make all
+    68 B count; the step API at 65 536 lanes (a 62 MB working set) moves nothing to HBM in steady state; at 4 M lanes it all counts."""
+    import types
+
+    import bench
+    ring = lambda slots, A, ld: torch.empty(slots, A, ld, dtype=torch.float32, device="meta")
+    wl = types.SimpleNamespace(mode="rollout", outputs="full", S=12, A=3, B=65536, P=250, R=64, env=types.SimpleNamespace(ld=65536),
+                               rings=[ring(64, 3, 65536)])
+    b, why = bench.hbm_side_bytes(wl)
+    assert b == 56 and why["outputs_footprint_bytes"] == 56 * 250 * 65536 and why["action_ring_footprint_bytes"] == 64 * 3 * 65536 * 4
+    wl.rings = [ring(250, 3, 65536) for _ in range(3)]
+    assert bench.hbm_side_bytes(wl)[0] == 68
+    wl.outputs, wl.rings = "min", [ring(64, 3, 65536)]
+    assert bench.hbm_side_bytes(wl)[0] == 0                      # 131 MB of reward + flag rows, 50 MB ring: all inside the cache
+    pg = types.SimpleNamespace(mode="rollout", outputs="full", S=32, A=8, B=262144, P=250, R=34, env=types.SimpleNamespace(ld=262144),
+                               rings=[ring(34, 8, 262144)])
+    assert bench.hbm_side_bytes(pg)[0] == 168                    # the PowerGrid record's 285 MB ring is larger than the cache
+    st = types.SimpleNamespace(mode="graph", outputs="full", S=12, A=3, B=65536, P=250, R=64, env=types.SimpleNamespace(ld=65536), rings=[])
+    assert bench.hbm_side_bytes(st)[0] == 0
+    st.B, st.env.ld = 4194304, 4194304
+    assert bench.hbm_side_bytes(st)[0] == bench.alg_bytes_per_step(12, 3) == 124
+
+
+def test_phase_stats_cuts_a_kernel_trace_at_the_lines_own_launch_counts(tmp_path):
+    """profiles/phase_stats.py: the headline kernel's launches of a profiled bench run, split by rank_times.phases."""
+    import json
+    import subprocess
+    import sys
+    name = "void nig::split_rollout_kernel<nig::ChemicalReactor, 3, 4, false>(nig::RolloutArgs)"
+    durs = [200] * 3 + [170] * 2 + [168] * 4 + [210] * 4            # settle, warm-up, timed, cold
+    rows, t = ['"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"'], 1000
+    for d in durs:
+        rows.append(f'"KERNEL_DISPATCH","{name}",{t},{t + d * 1000}')
+        t += d * 1000 + 500
+    rows.insert(3, '"KERNEL_DISPATCH","void nig::fill_actions_kernel<nig::ChemicalReactor>(float*)",5,9')
+    (tmp_path / "trace.csv").write_text("\n".join(rows) + "\n")
+    line = {"ms_per_step": 0.1705, "roofline": {"kernel": "split_rollout_kernel<ChemicalReactor,3,4>", "launch_us": 168.9},
+            "rank_times": {"phases": [{"name": "settle", "launches": 3}, {"name": "warmup", "launches": 2}, {"name": "timed", "launches": 4},
+                                      {"name": "cold_first_launches", "launches": 4}]}}
+    (tmp_path / "bench.json").write_text("some stderr noise\n" + json.dumps(line) + "\n")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "phase_stats.py"), str(tmp_path / "trace.csv"),
+                        str(tmp_path / "bench.json"), str(tmp_path / "out.csv")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = (tmp_path / "out.csv").read_text().splitlines()
+    got = {l.split(",")[0]: l for l in out[1:] if not l.startswith("#")}
+    assert ",3,200.00," in got["settle"] and ",2,170.00," in got["warmup"] and ",4,168.00," in got["timed"] and ",4,210.00," in got["cold_first_launches"]
+    assert "timed phase: 168.00 us" in out[-1] and "WARNING" not in p.stderr
+
+
+def test_bench_pins_ranks_to_disjoint_cpu_shares(monkeypatch):
+    """bench.pin_rank: without topology information every local rank gets an even contiguous share of the allowed CPUs; a single
+    rank (or too few CPUs) is left alone; a failure is reported, never raised."""
+    import bench
+    allowed = set(range(16))
+    seen = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(allowed))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: seen.__setitem__("cpus", list(cpus)))
+    monkeypatch.setattr(bench, "gpu_numa_nodes", lambda: None)
+    r0, r3 = bench.pin_rank(0, 4), None
+    assert r0["pinned"] and seen["cpus"] == [0, 1, 2, 3]
+    r3 = bench.pin_rank(3, 4)
+    assert r3["pinned"] and seen["cpus"] == [12, 13, 14, 15] and r3["how"] == "even-split"
+    assert bench.pin_rank(0, 1)["pinned"] is False
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: (_ for _ in ()).throw(OSError("no")))
+    assert bench.pin_rank(1, 4)["pinned"] is False
+
+
 def test_bench_does_not_spawn_under_a_profiler_preload():
     """A rocprofv3 preload initialises the GPU before main(): spawning the ranks from that process would be an exec from a
     GPU-initialised process (forbidden on this pool) -- bench.py refuses with a message instead."""

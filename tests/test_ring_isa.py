@@ -33,6 +33,9 @@ KERNELS = [   # (translation unit, mangled-name fragment, counters that publish 
     ("env_cr", "split_rollout_kernelINS_15ChemicalReactorELi3ELi4ELb0E", {0, 1}, {2}),
     ("env_ra", "split_rollout_kernelINS_13RobotAssemblyELi3ELi4ELb0E", {0, 1}, {2}),
     ("env_cr", "split_policy_kernelINS_15ChemicalReactorELi4E", {0, 1}, {2}),
+    ("env_ra", "split_policy_kernelINS_13RobotAssemblyELi4E", {0, 1}, {2}),
+    ("env_pg", "rollout_pg_pair_policy_kernelINS_10PolicyArgsE", {0}, {1}),
+    ("env_pg", "rollout_pg_pair_kernelILi1ELb0ELb1E", {0}, {1}),
     ("env_pg", "rollout_pg_pair_kernelILi3ELb0E", {0}, {1}),
 ]
 
