@@ -127,7 +127,8 @@ typedef struct nig_handle nig_handle;
 
 /* "nig <major.minor.patch> (gfx950; generator <id>)".  The generator id names the fast-mode random stream: trajectories of a
  * given (seed, lane, launch counter) are reproducible only under the same id ("nig-philox-v1" up to 0.1.0; "nig-philox-v2":
- * Philox4x32-7, float32 reset draws, since 0.2.0). */
+ * Philox4x32-7, float32 reset draws, 0.2.0; "nig-philox-v3", since 0.3.0: v2 with PowerGrid's eight reset load factors taken as
+ * 16-bit uniforms from the low bytes of its reset normals' words -- only PowerGrid trajectories differ from v2). */
 const char *nig_version(void);
 const char *nig_last_error(void);
 

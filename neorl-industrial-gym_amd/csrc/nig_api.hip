@@ -305,9 +305,12 @@ unsigned wide_min_blocks_for(unsigned cus)
 
 extern "C" {
 
-// 0.2.0: the fast-mode generator is "nig-philox-v2" (Philox4x32-7, float32 reset draws for ChemicalReactor / PowerGrid, round 3):
-// every (seed, lane, t) trajectory differs from 0.1.0's "nig-philox-v1" -- stored seeds / datasets are tied to the generator id
-const char *nig_version(void) { return "nig 0.2.0 (gfx950; generator nig-philox-v2)"; }
+// 0.2.0: the fast-mode generator became "nig-philox-v2" (Philox4x32-7, float32 reset draws for ChemicalReactor / PowerGrid, round 3):
+// every (seed, lane, t) trajectory differs from 0.1.0's "nig-philox-v1" -- stored seeds / datasets are tied to the generator id.
+// 0.3.0, "nig-philox-v3" (round 4): as v2, except that PowerGrid's eight RESET load factors are 16-bit uniforms taken from the
+// low bytes of the reset normals' words (six Philox blocks per reset instead of eight): PowerGrid trajectories differ from v2's
+// from the first auto-reset on; ChemicalReactor, RobotAssembly and every other env are bit-identical to v2.
+const char *nig_version(void) { return "nig 0.3.0 (gfx950; generator nig-philox-v3)"; }
 const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)

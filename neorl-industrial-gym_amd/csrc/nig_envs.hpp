@@ -40,7 +40,7 @@ struct ChemicalReactor {
     // for one or two active lanes: ~50 instructions per wave-step on average, 14 % of the step.  Cooperative form:
     // work item = (lane, generator block) -> four state rows through a wave-private LDS image: one short pass.
     static constexpr bool COOP_RESET = true;
-    static constexpr int RESET_ITEMS_LOG2 = 1, RESET_ROWS = 8;
+    static constexpr int RESET_ITEMS = 2, RESET_ROWS = 8;
     using fast_noise_t = double;
     static constexpr int ID = 0, S = 12, A = 3, KS = 2, KR = 8, MAX_STEPS = 500;
     static constexpr bool COMPACT_RESET = false;
@@ -262,7 +262,7 @@ struct PowerGrid {
     // (lane, generator block) -> 4 state rows, through a wave-private LDS image -- no block barrier, and
     // ~70 % lane utilisation instead of a whole wave running the 8-block reset path for a few lanes.
     static constexpr bool COMPACT_RESET = false, COOP_RESET = true;
-    static constexpr int RESET_ITEMS_LOG2 = 3, RESET_ROWS = S;   // 8 generator blocks per reset: 6 of normals, 2 of uniforms
+    static constexpr int RESET_ITEMS = 6, RESET_ROWS = S;   // 6 generator blocks per reset ("nig-philox-v3": the 8 load factors ride in the normals' spare low bytes; v2 drew 2 more blocks for them)
     static constexpr bool SHARED_STEP_BLOCK = false;
     // Fast-mode step noise stays float32 (sd * z is a float32 product): (float)((double)s + (double)n32) is the
     // correctly rounded float32 sum s + n32 for ANY two floats (exact in double when the exponents are within
@@ -305,19 +305,31 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < 7; ++i) s[25 + i] = (float)n[24 + i];        // :108
     }
+    // A load factor's uniform: 16 bits = the low bytes of two words of a reset block (bits 7..0: below the 24 bits a normal
+    // takes), as the float32 k / 65536 -- one of the 24-bit uniforms (k << 8) / 2^24, so what was proven for those holds.
+    // "nig-philox-v3" (round 4): v2 drew blocks STREAM_RESET + 16 / + 17 for the eight factors -- two of a reset's eight blocks.
+    __device__ static float load_factor(uint32_t w_lo, uint32_t w_hi)
+    {
+        const uint32_t k16 = __builtin_amdgcn_perm(w_hi, w_lo, 0x0c0c0400u);   // byte 0 of w_lo, byte 0 of w_hi, zeros
+        return __builtin_fmaf(0.4f / 65536.0f, (float)k16, -0.2f);           // uniform(-0.2, 0.2): low + (high - low) * u, u = k16 / 65536 (the scale is a power of two: same rounding)
+    }
     __device__ static void draw_init(const RngKey &k, double (&n)[KR])
     {
-        // "nig-philox-v2": float32 draws (normals sd * z; the load factor fma(0.4, u, -0.2) with u the 24-bit uniform,
-        // exact in float32), widened to the doubles init() takes -- see reset_item_to for what that buys
-        float z[23];
-        double u[8];
-        gen_normals<23>(k, STREAM_RESET, z);
-        gen_uniforms<8>(k, STREAM_RESET + 16u, u);
+        // float32 draws (normals sd * z; the load factor fma(0.4, u, -0.2), exact in float32), widened to the doubles init()
+        // takes -- see reset_item_to for what that buys.  Blocks 0-5 of the reset stream, words in order: the 23 normals;
+        // block b < 4 also carries load factors 2 b and 2 b + 1 in the low bytes of its words (0, 1) and (2, 3).
+        float z[24];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const u32x4 x = k.block(STREAM_RESET + (uint32_t)j);
+            z[4 * j] = probit_normal(x.x, k.tab); z[4 * j + 1] = probit_normal(x.y, k.tab); z[4 * j + 2] = probit_normal(x.z, k.tab);
+            z[4 * j + 3] = (j < 5) ? probit_normal(x.w, k.tab) : 0.0f;          // z[23] does not exist
+            if (j < 4) { n[16 + 2 * j] = (double)load_factor(x.x, x.y); n[17 + 2 * j] = (double)load_factor(x.z, x.w); }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             n[i] = (double)(0.01f * z[i]);
             n[8 + i] = (double)(2.0f * z[8 + i]);
-            n[16 + i] = (double)__builtin_fmaf(0.4f, (float)u[i], -0.2f);      // uniform(-0.2, 0.2): low + (high - low) * u
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) n[24 + i] = (double)(10.0f * z[16 + i]);
@@ -346,10 +358,10 @@ struct PowerGrid {
 #pragma unroll
         for (int i = 0; i < KS; ++i) n[i] = (double)z[i];
     }
-    // One work item of a cooperative reset: generator block `blk` of the lane with key `k` -> the four state
-    // rows its words feed, stored into column `col` (= img + owner lane) of a [RESET_ROWS][64] image.  Same values,
-    // operation by operation, as draw_init + init.  Blocks 0-5: normals z[4 blk + q] (V, gen, line flows);
-    // blocks 6-7: uniforms u[4 (blk - 6) + q] (loads).  Block 0 also clears row 0 (freq_dev).
+    // One work item of a cooperative reset: generator block `blk` (0-5) of the lane with key `k` -> the four state rows its
+    // words feed (normals z[4 blk + q]: V, gen, line flows) and, for blk < 4, the two load rows whose factors ride in its words'
+    // low bytes, stored into column `col` (= img + owner lane) of a [RESET_ROWS][64] image.  Same values, operation by
+    // operation, as draw_init + init.  Block 0 also clears row 0 (freq_dev).
     // (A two-phase form with a 16-row image was tried: the rows read back in phase 0 stay live across phase 1's
     // items and pushed the rollout kernel into scratch spills: -13 %.)
     __device__ static void reset_item(const RngKey &k, uint32_t blk, float *img, unsigned owner)
@@ -361,30 +373,28 @@ struct PowerGrid {
     template <class Put>
     __device__ static void reset_item_to(const RngKey &k, uint32_t blk, Put &&put)
     {
-        const bool uni = blk >= 6u;
-        const u32x4 x = k.block(STREAM_RESET + (uni ? 10u + blk : blk));     // uniforms: STREAM_RESET + 16 + (blk - 6)
+        const u32x4 x = k.block(STREAM_RESET + blk);
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
         const bool hi = (blk & 1u) != 0;                                     // second half of an 8-vector
         // init() of draw_init()'s values without a float64 instruction: with a float32 draw d and a float32-representable
         // offset, (float)(off + (double)d) is the exactly computed sum rounded once = off + d in float32, and
         // (float)(b * (1.0 + (double)d)) = the exactly computed b + b d rounded once = fma(b, d, b).
-        if (!uni) {
-            // V 1.0 + 0.01 z (:98), gen base_load + 2.0 z (:101), flows 10.0 z (:108)
-            const float sd = blk < 2u ? 0.01f : (blk < 4u ? 2.0f : 10.0f);
-            const uint32_t row0 = (blk < 4u ? 1u : 9u) + 4u * blk;
+        // V 1.0 + 0.01 z (:98), gen base_load + 2.0 z (:101), flows 10.0 z (:108)
+        const float sd = blk < 2u ? 0.01f : (blk < 4u ? 2.0f : 10.0f);
+        const uint32_t row0 = (blk < 4u ? 1u : 9u) + 4u * blk;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float off = blk < 2u ? 1.0f : (blk < 4u ? (float)(hi ? base_load(4 + q) : base_load(q)) : 0.0f);
-                const float v = off + sd * probit_normal(w[q], k.tab);      // flows: 0.0 + d == d (d is never -0.0)
-                if (q < 3 || blk != 5u) put(row0 + (uint32_t)q, v);   // z[23] does not exist
-            }
-            if (blk == 0u) put(0u, 0.0f);
-        } else {
+        for (int q = 0; q < 4; ++q) {
+            const float off = blk < 2u ? 1.0f : (blk < 4u ? (float)(hi ? base_load(4 + q) : base_load(q)) : 0.0f);
+            const float v = off + sd * probit_normal(w[q], k.tab);      // flows: 0.0 + d == d (d is never -0.0)
+            if (q < 3 || blk != 5u) put(row0 + (uint32_t)q, v);   // z[23] does not exist
+        }
+        if (blk == 0u) put(0u, 0.0f);
+        if (blk < 4u) {                                                      // loads 2 blk, 2 blk + 1: base * (1 + factor), :104-105
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float nn = __builtin_fmaf(0.4f, u01f(w[q]), -0.2f);    // :104 uniform(-0.2, 0.2)
-                const float b = (float)(hi ? base_load(4 + q) : base_load(q));
-                put(17u + 4u * (blk - 6u) + (uint32_t)q, __builtin_fmaf(b, nn, b));   // :105 base * (1 + factor)
+            for (int q = 0; q < 2; ++q) {
+                const float nn = load_factor(w[2 * q], w[2 * q + 1]);
+                const float b = (float)(blk == 0u ? base_load(q) : blk == 1u ? base_load(2 + q) : blk == 2u ? base_load(4 + q) : base_load(6 + q));
+                put(17u + 2u * blk + (uint32_t)q, __builtin_fmaf(b, nn, b));
             }
         }
     }
@@ -398,13 +408,23 @@ struct PowerGrid {
     // module-level check functions :10-30 (pre-state, clipped action)
     __device__ static uint32_t violated(const float (&s)[S], const float (&a)[A])
     {
-        bool v_ok = true, g_ok = true;
+        // all(0.95 <= V <= 1.05) and all(0 <= gen + a <= 100) as "smallest >= lower bound and largest <= upper bound" over
+        // minimum / maximum trees of v_minimum3_f32 / v_maximum3_f32 (IEEE 754-2019 minimum / maximum: a NaN anywhere makes
+        // both NaN and both compares false -- exactly what the element-wise `all` does with a NaN; eight instructions + two
+        // compares per check where sixteen compares and their scalar ands were)
+        float vmn = s[1], vmx = s[1];
+        float ng0 = s[9] + a[0];                                         // float32 add, :29
+        float gmn = ng0, gmx = ng0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v_ok = v_ok & (s[1 + i] >= 0.95f) & (s[1 + i] <= 1.05f);     // weak Python floats -> float32.  (& not &&: hipcc turns a long short-circuit chain into a cascade of exec-mask branches)
-            const float ng = s[9 + i] + a[i];                            // float32 add, :29
-            g_ok = g_ok & (ng >= 0.0f) & ((double)ng <= 100.0);          // vs fp64 array np.ones(8)*100
+        for (int i = 1; i < 8; ++i) {
+            vmn = __builtin_elementwise_minimum(vmn, s[1 + i]);           // weak Python floats -> float32
+            vmx = __builtin_elementwise_maximum(vmx, s[1 + i]);
+            const float ng = s[9 + i] + a[i];
+            gmn = __builtin_elementwise_minimum(gmn, ng);
+            gmx = __builtin_elementwise_maximum(gmx, ng);
         }
+        const bool v_ok = (vmn >= 0.95f) & (vmx <= 1.05f);
+        const bool g_ok = (gmn >= 0.0f) & (gmx <= 100.0f);               // vs the fp64 array np.ones(8)*100: (double)x <= 100.0 == x <= 100.0f
         uint32_t v = (fabsf(s[0]) < 0.5f) ? 0u : 1u;                     // :14
         v |= v_ok ? 0u : 2u;
         v |= g_ok ? 0u : 4u;
@@ -539,10 +559,12 @@ struct PowerGrid {
     // _is_done :179-192
     __device__ static bool done_fv(float f, const float (&v)[8])
     {
-        bool bad = fabsf(f) > 1.0f;
+        // any(V < 0.9) or any(V > 1.1) as "smallest < 0.9 or largest > 1.1" over v_min3_f32 / v_max3_f32 trees (IEEE minNum /
+        // maxNum: a NaN element is passed over, as the element-wise compares pass it over; all NaN -> NaN -> both false)
+        float mn = v[0], mx = v[0];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bad = bad | (v[i] < 0.9f) | (v[i] > 1.1f);
-        return bad;
+        for (int i = 1; i < 8; ++i) { mn = __builtin_fminf(mn, v[i]); mx = __builtin_fmaxf(mx, v[i]); }
+        return (fabsf(f) > 1.0f) | (mn < 0.9f) | (mx > 1.1f);
     }
     __device__ static bool done(const float (&n)[S])
     {
@@ -563,7 +585,7 @@ struct RobotAssembly {
     // uniform draw -> joint angle -> sincos -> link * cos / sin terms into a wave-private LDS image, the owner sums
     // them in the reference's order): no block barrier, one short pass instead of a 7-sincos path.
     static constexpr bool COOP_RESET = true;
-    static constexpr int RESET_ITEMS_LOG2 = 3;     // 7 joints (+ 1 idle item) per reset
+    static constexpr int RESET_ITEMS = 8;          // 7 joints (+ 1 idle item) per reset
     static constexpr int RESET_ROWS = 29;          // image per wave: 11 rows of 64 doubles (terms) + 7 rows of 64 floats (angles)
     using fast_noise_t = double;
     static constexpr int ID = 2, S = 24, A = 7, KS = 0, KR = 7, MAX_STEPS = 1000;

@@ -323,19 +323,23 @@ __device__ __forceinline__ void coop_reset(unsigned long long m, bool mine, unsi
                                            uint64_t lane_gi0, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                                            const float4 *tab, float (&n)[Env::S])
 {
-    constexpr int LOG2 = Env::RESET_ITEMS_LOG2;
+    constexpr int ITEMS = Env::RESET_ITEMS;                   // work items per finishing lane (a power of two, or 6)
+    static_assert((ITEMS & (ITEMS - 1)) == 0 || ITEMS == 6, "item index -> (lane, item): shift, or the divide-by-6 below");
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
     if (mine) lst[rank] = (unsigned char)lane;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const int total = __popcll(m) << LOG2;
+    const int total = __popcll(m) * ITEMS;
     for (int i = (int)lane; i < total; i += 64) {
         // The item index is laundered: in the first pass it equals the lane index, a loop invariant of the ROLLOUT loop
         // around this call, and hipcc then hoists every per-block constant select of reset_item (standard deviations,
         // offsets, row numbers: ~30 registers for PowerGrid) out of that loop and keeps them alive across the whole step.
         int ii = i;
         asm volatile("" : "+v"(ii));
-        const unsigned owner = lst[ii >> LOG2];
-        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), (uint32_t)ii & ((1u << LOG2) - 1u), img, owner);
+        unsigned li, item;                     // ii = li * ITEMS + item (ii < 64 * ITEMS)
+        if constexpr (ITEMS == 6) { li = ((unsigned)ii * 171u) >> 10; item = (unsigned)ii - 6u * li; }     // exact for ii < 515
+        else { li = (unsigned)ii / (unsigned)ITEMS; item = (unsigned)ii % (unsigned)ITEMS; }
+        const unsigned owner = lst[li];
+        Env::reset_item(make_key(lane_gi0 + owner, t, seed_lo, seed_hi, tab), item, img, owner);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (mine) Env::reset_readback(img, lane, n);

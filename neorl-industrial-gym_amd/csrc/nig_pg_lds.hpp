@@ -542,14 +542,15 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // finishing lanes below this one (v_mbcnt: no per-lane mask register)
                 if (done) wl[rank] = (unsigned char)lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                const int total = __popcll(m) << 3;
+                const int total = __popcll(m) * Env::RESET_ITEMS;            // six items per finishing lane
                 for (int i = (int)lane; i < total; i += 64) {
                     int ii = i;
                     asm volatile("" : "+v"(ii));   // not a loop invariant of the rollout loop: see coop_reset
-                    const unsigned owner = wl[ii >> 3];
+                    const unsigned li = ((unsigned)ii * 171u) >> 10;                 // ii / 6, exact for ii < 515
+                    const unsigned owner = wl[li];
                     float *row = imgf + ((owner >> 3) * 64u + (owner & 7u)) * 4u;
                     Env::reset_item_to(make_key(wave_gi0 + owner, t_base + (uint32_t)it + 1u, p.seed_lo, p.seed_hi, s_probit),
-                                       (uint32_t)ii & 7u, [row](uint32_t k, float v) { row[(k >> 2) * 32u + (k & 3u)] = v; });
+                                       (unsigned)ii - 6u * li, [row](uint32_t k, float v) { row[(k >> 2) * 32u + (k & 3u)] = v; });
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }

@@ -1201,11 +1201,23 @@ void oracle_gen_reset_noise(int env, uint64_t seed, uint64_t env_index, uint32_t
          * (exact in float32) -- handed to _get_initial_state's fp64 arithmetic as doubles.  (float)(1.0 + d), (float)(base + d)
          * and (float)(base * (1.0 + d)) are then exact-in-double sums / products rounded once: on the device one
          * v_add_f32 / v_fma_f32 each. */
+        /* "nig-philox-v3" (round 4): the eight load factors are 16-bit uniforms k / 65536 taken from the LOW BYTES of the reset
+         * normals' words -- block b < 4 of the reset stream carries factors 2 b (byte 0 of words 0, 1) and 2 b + 1 (words 2, 3) --
+         * instead of two more Philox blocks (v2: STREAM_RESET + 16 / + 17).  k / 65536 = (k << 8) / 2^24 is one of v2's 24-bit
+         * uniforms, so the exactness statements above are unchanged. */
         gen_normals(seed, env_index, t, STREAM_RESET, 23, z);
-        gen_uniforms(seed, env_index, t, STREAM_RESET + 16u, 8, u);
+        for (int b = 0; b < 4; b++) {
+            uint32_t x[4];
+            philox4x32_r(PHILOX_ROUNDS, (uint32_t)env_index, (uint32_t)(env_index >> 32), t, STREAM_RESET + (uint32_t)b,
+                          (uint32_t)seed, (uint32_t)(seed >> 32), x);
+            for (int q = 0; q < 2; q++) {
+                const uint32_t k16 = (x[2 * q] & 0xFFu) | ((x[2 * q + 1] & 0xFFu) << 8);
+                noise[16 + 2 * b + q] = (double)fmaf(0.4f / 65536.0f, (float)k16, -0.2f);
+            }
+        }
+        (void)u;
         for (int i = 0; i < 8; i++) noise[i] = (double)(0.01f * z[i]);
         for (int i = 0; i < 8; i++) noise[8 + i] = (double)(2.0f * z[8 + i]);
-        for (int i = 0; i < 8; i++) noise[16 + i] = (double)fmaf(0.4f, (float)u[i], -0.2f);
         for (int i = 0; i < 7; i++) noise[24 + i] = (double)(10.0f * z[16 + i]);
     } else if (env == ORACLE_RA) {                             /* robot_assembly.py:118-122 */
         gen_uniforms(seed, env_index, t, STREAM_RESET, 7, u);
