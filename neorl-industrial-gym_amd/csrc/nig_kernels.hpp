@@ -1601,8 +1601,15 @@ constexpr int MLP_STREAM_FLOATS = MLP_CHUNKS * MLP_CHREC * 64;
 typedef __attribute__((address_space(3))) void nig_lds_void;
 typedef __attribute__((address_space(1))) const void nig_glb_void;
 
+// Two blocks per CU (round 4): the double-buffered weight image is 74 KiB per block; with the generator's 12 KiB table beside it
+// only ONE block fitted a CU's 160 KiB, i.e. one wave per SIMD, and every chunk barrier and ring refill was exposed MFMA idle
+// time (duty cycle 0.78, profiles/r04/mlp_cr65536_sq.txt).  An env with a couple of draws per step (KS <= 4) reads its table
+// entries from global memory (L2-resident, as step_kernel does) and the kernel is compiled for two waves per SIMD, so a second
+// block's waves fill the first's bubbles.
+template <class Env> constexpr bool mlp_two_blocks = true;       // (PowerGrid's 23 + 31 table reads per step / reset from L2 as well: they are noise beside 1 217 MFMAs)
+
 template <class Env>
-__global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
+__global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_mlp_kernel(const MlpArgs q)
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
@@ -1614,7 +1621,12 @@ __global__ void __launch_bounds__(BLOCK, 1) rollout_mlp_kernel(const MlpArgs q)
     // quarter of the pieces, the fill of chunk c+1 in flight while chunk c is consumed; an MFMA's A operand is one
     // ds_read_b32.  L2 traffic per block and step: 311 KB instead of 4 x 311 KB.
     __shared__ __attribute__((aligned(16))) float s_w[2][MLP_CHREC * 64];
-    NIG_STAGE_PROBIT(s_probit);
+    __shared__ float4 s_probit_[mlp_two_blocks<Env> ? 1 : 768];
+    if constexpr (!mlp_two_blocks<Env>) {
+        for (int i_ = (int)threadIdx.x; i_ < 768; i_ += BLOCK) s_probit_[i_] = NIG_PROBIT[i_];
+        __syncthreads();
+    }
+    const float4 *const s_probit = mlp_two_blocks<Env> ? NIG_PROBIT : s_probit_;
     const StepArgs &p = q.s;
     const unsigned tid = threadIdx.x, lane = tid & 63u, half = lane >> 5, e = lane & 31u, wave = tid >> 6;
     const uint32_t lane0 = blockIdx.x * (BLOCK / 2) + (tid >> 6) * 32u;     // first env of this wave
