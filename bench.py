@@ -467,6 +467,23 @@ def pin_rank(local_rank, local_world):
                 i = peers.index(local_rank)
                 mine, how = cpus[i * share:(i + 1) * share], f"numa node {node}"
         if not mine:
+            # no GPU -> NUMA map: ranks in order over the NUMA nodes in order (GPUs 0..N/2-1 hang off the first socket on the
+            # usual two-socket node), each rank an even share of ITS node's CPUs -- a node's cpulist holds its cores and their
+            # SMT siblings, which a plain split of the CPU numbers would hand to different sockets' ranks
+            try:
+                nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+                per = [[c for c in _cpulist(open(f"/sys/devices/system/node/node{n}/cpulist").read()) if c in set(allowed)] for n in nodes]
+                per = [c for c in per if c]
+                if len(per) > 1 and local_world % len(per) == 0:
+                    rpn = local_world // len(per)                   # ranks per node
+                    cpus = per[local_rank // rpn]
+                    share = len(cpus) // rpn
+                    if share >= 1:
+                        i = local_rank % rpn
+                        mine, how = cpus[i * share:(i + 1) * share], f"numa node {local_rank // rpn} of {len(per)} (ranks in node order)"
+            except Exception:
+                mine = None
+        if not mine:
             share = len(allowed) // local_world
             mine = allowed[local_rank * share:(local_rank + 1) * share]
         os.sched_setaffinity(0, mine)

@@ -38,7 +38,7 @@ def _chain(d, B, T):
     rz = np.zeros((T, KR, B))
     idx = np.zeros((T, B), np.int64)            # fixture row of (step, lane)
     first = np.zeros(B, np.int64)
-    for l in range(B):
+    for l in range(min(B, E)):                  # lane l and lane l + E play the same episodes: build E lanes, tile below
         e, t = l % E, 0
         first[l] = e
         while t < T:
@@ -52,6 +52,10 @@ def _chain(d, B, T):
             rz[t:t + n, :, l] = d["ep_init_noise"][nxt]      # only the episode's last step consumes it
             t += n
             e = nxt
+    for l0 in range(E, B, E):
+        w = min(E, B - l0)
+        act[:, :, l0:l0 + w] = act[:, :, :w]; nz[:, :, l0:l0 + w] = nz[:, :, :w]; rz[:, :, l0:l0 + w] = rz[:, :, :w]
+        idx[:, l0:l0 + w] = idx[:, :w]; first[l0:l0 + w] = first[:w]
     return act, nz, rz, idx, first
 
 
@@ -59,6 +63,9 @@ FORMS = [
     # (id, env key, lanes, steps, tune(split_blocks, wide_min_blocks), autoreset, kernel bench.rollout_kernel_name must report)
     ("three-wave-cr", "cr", 256, 1300, (256, 256), True, "split_rollout_kernel<ChemicalReactor,3,4>"),
     ("three-wave-ra", "ra", 256, 240, (256, 256), True, "split_rollout_kernel<RobotAssembly,3,4>"),
+    # the BASELINE headline shape: one 256-lane block per compute unit, every ring of the chip under contention
+    ("three-wave-cr-65536", "cr", 65536, 120, (256, 256), True, "split_rollout_kernel<ChemicalReactor,3,4>"),
+    ("wide-512-pg-262144", "pg", 262144, 24, (256, 256), True, "rollout_wide_kernel<PowerGrid,3,512>"),
     ("wide-512-pg", "pg", 1024, 96, (0, 1), True, "rollout_wide_kernel<PowerGrid,3,512>"),
     ("wide-256-pg", "pg", 512, 96, (0, 256), True, "rollout_wide_kernel<PowerGrid,3,256>"),
     ("pair-pg", "pg", 512, 96, (256, 256), True, "rollout_pg_pair_kernel<3>"),
@@ -140,11 +147,14 @@ def test_recorded_reference_rollouts_through_the_fused_kernels(ni, form):
     n_done = (done & live).sum(0)
     assert np.array_equal(tally[L.T_EPISODES], n_done)
     viol_done = np.zeros(B); len_done = np.zeros(B); ret_done = np.zeros(B)
-    for l in range(B):
+    for l in range(min(B, E)):
         e = first[l]
         for _ in range(int(n_done[l])):
             viol_done[l] += d["ep_viol"][e]; len_done[l] += d["ep_length"][e]; ret_done[l] += d["ep_return"][e]
             e = (e + 1) % E
+    for l0 in range(E, B, E):
+        w = min(E, B - l0)
+        viol_done[l0:l0 + w] = viol_done[:w]; len_done[l0:l0 + w] = len_done[:w]; ret_done[l0:l0 + w] = ret_done[:w]
     assert np.array_equal(tally[L.T_VIOL], viol_done) and np.array_equal(tally[L.T_LEN_SUM], len_done)
     assert rel_err(tally[L.T_RET_SUM], ret_done, floor=1e-3).max() <= RTOL
     # base.py:183 total_violations: every violation so far, the running episode's included
