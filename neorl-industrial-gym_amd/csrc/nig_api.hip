@@ -154,6 +154,7 @@ struct nig_handle {
     char *hst_pinned;      // host-buffer entry points: pinned staging + its device mirror (owned, lazy)
     char *hst_dev;
     size_t hst_bytes;
+    float *mirror; uint32_t ld_mirror;    // StepArgs::mirror of the next step launch (nig_step_host*), else NULL
 };
 
 struct nig_plan {
@@ -237,6 +238,7 @@ static StepArgs base_step_args(const nig_handle *h)
     a.max_steps = h->max_steps; a.dt32 = (float)h->dt; a.dt = h->dt; a.cmask = h->cmask;
     a.hflags = h->flags | (h->may_hold_done ? HF_MAY_HOLD_DONE : 0u);
     a.n_en = enabled_constraints(h);
+    a.mirror = h->mirror; a.ld_mirror = h->ld_mirror;      // (set by the host-buffer entry points around their step launch)
 #ifdef NIG_RING_SPIN_LIMIT
     a.ring_err = h->t_dev + 16;                    // a spare word of the 256-byte launch-counter slot (zeroed at nig_create)
     if (nig::g_diag_ring_fault.load(std::memory_order_relaxed)) a.hflags |= HF_DIAG_RING_FAULT;
@@ -441,7 +443,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
     h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false; h->mlp_stream = nullptr; h->act32 = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0;
+    h->has_policy = false; h->mlp_stream = nullptr; h->act32 = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0; h->mirror = nullptr; h->ld_mirror = 0;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -903,14 +905,15 @@ static int step_host_impl(nig_handle *h, const void *actions, bool act64, const 
     char *io = zero_copy ? h->hst_pinned : h->hst_dev;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_dev, h->hst_pinned, up, hipMemcpyHostToDevice, st));
     if (dn) dn = (const double *)(io + L.off_noise);
+    h->mirror = (float *)(io + L.off_state); h->ld_mirror = (uint32_t)B;
     rc = act64 ? nig_step64(h, (const double *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
                             (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream)
                : nig_step(h, (const float *)(io + L.off_act), (int64_t)B, dn, nullptr, (int64_t)B, nullptr,
                           (double *)(io + L.off_rew), (uint32_t *)(io + L.off_flags), nullptr, 0, stream);
+    h->mirror = nullptr;
     if (rc != NIG_OK) return rc;
-    // state rows gathered next to reward64 and flags: one download for everything the call returns
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(h->B)), dim3(BLOCK), 0, st, (const float *)h->state, h->ld_state,
-                       (float *)(io + L.off_state), (int64_t)B, sp.state_dim, h->B);
+    // (the state rows land next to reward64 and flags -- one download for everything the call returns -- written by the step
+    // kernel itself: StepArgs::mirror.  Until round 4 a row-gather kernel was launched behind every step for them.)
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->hst_pinned + L.off_state, h->hst_dev + L.off_state, L.bytes - L.off_state, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     memcpy(state_out, h->hst_pinned + L.off_state, (size_t)sp.state_dim * B * 4);

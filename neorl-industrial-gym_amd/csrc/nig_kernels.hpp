@@ -68,6 +68,9 @@ struct StepArgs {
     // host side only (which kernel form a launch takes, nig_tune): thresholds in effect for this handle's device
     uint32_t split_blocks, wide_min_blocks;
     uint32_t *ring_err;               // device word a timed-out ring wait is reported in (NIG_RING_SPIN_LIMIT builds only; nig_ring.hpp)
+    // nig_step_host: a second copy of every lane's post-step state rows, [S][ld_mirror], written by the step kernel itself
+    // (the host-buffer entry points used to launch a row-gather kernel behind every step: one launch less per env.step)
+    float *mirror; uint32_t ld_mirror;
 };
 // internal bit of StepArgs::hflags (above the public NIG_F_* bits): some lane of the handle may hold
 // NIG_CTR_DONE although the handle auto-resets (never reset, left out by reset(mask), set by
@@ -529,6 +532,10 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
                 float *so = p.state + base;
 #pragma unroll
                 for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
+                if (p.mirror) {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) (p.mirror + base + k * p.ld_mirror)[tid] = n[k];
+                }
             }
         }
         (p.ctr + base)[tid] = nctr;
@@ -540,6 +547,10 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
         if (p.flags) (p.flags + base)[tid] = NIG_FLAG_INACTIVE | ((ctr & NIG_CTR_STEP_MASK) << NIG_FLAG_STEP_SHIFT);
         if (p.reward) (p.reward + base)[tid] = 0.0f;
         if (p.reward64) (p.reward64 + base)[tid] = 0.0;
+        if (p.mirror) {                           // a frozen lane: its state as it stands
+#pragma unroll
+            for (int k = 0; k < S; ++k) (p.mirror + base + k * p.ld_mirror)[tid] = s[k];
+        }
     }
 
     if constexpr (COOP) {
@@ -563,6 +574,10 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
             float *so = p.state + base;
 #pragma unroll
             for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tid] = n[k];
+            if (p.mirror) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) (p.mirror + base + k * p.ld_mirror)[tid] = n[k];
+            }
         }
         return;
     }
@@ -594,6 +609,10 @@ __global__ void __launch_bounds__(HELP ? 2 * BLK : BLK, (ACT64 || HELP ? 2 : (BL
         float *so = p.state + base;
 #pragma unroll
         for (int k = 0; k < S; ++k) (so + k * p.ld_state)[tl] = r0[k];
+        if (p.mirror) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) (p.mirror + base + k * p.ld_mirror)[tl] = r0[k];
+        }
     }
 }
 
