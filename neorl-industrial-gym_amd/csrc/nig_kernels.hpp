@@ -1069,6 +1069,8 @@ template <class Env> __device__ __forceinline__ void policy_draws(const nig_poli
 template <int A, class PV> __device__ __forceinline__ void policy_switches(const PV *__restrict__ P, bool &any_sigma, bool &any_half, bool &mix);
 template <class Env, class PV> __device__ __forceinline__ void policy_affine(const PV *__restrict__ P, const float (&obs)[Env::S], float (&u)[Env::A]);
 template <class Env, class PV> __device__ __forceinline__ void policy_finish(const PV *__restrict__ P, const PolicyDraws<Env::A> &d, float (&u)[Env::A]);
+template <class Env, class PV> __device__ __forceinline__ void policy_finish_sw(const PV *__restrict__ P, bool any_sigma, bool any_half, bool mix, float lo, float hi,
+                                                                                const PolicyDraws<Env::A> &d, float (&u)[Env::A]);
 
 // Register copy of the policy fields a closed-loop form reads every step besides the feedback matrix (same field names as
 // nig_policy: policy_finish / policy_switches take either).  Read in place from LDS, every field was an exposed ds_read round

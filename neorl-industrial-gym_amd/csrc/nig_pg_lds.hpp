@@ -619,6 +619,109 @@ __global__ void __launch_bounds__(512, 2) rollout_pg_pair_kernel(const RolloutAr
     } else pg_lds_rollout_body<OUT, 256, true, NOISE>(q, base, smem);
 }
 
+// The closed loop's stepping wave with its state in REGISTERS (paired form, calls WITHOUT the observation stream): the loop of
+// rollout_policy_kernel -- feedback law, IndustrialEnv.step, bookkeeping, cooperative reset, the same calls on the same values --
+// with the step's normals and the policy's draws read from the producer's slot and the feedback matrix from the dense LDS copy.
+// At the pair form's two waves per SIMD a wave may hold 256 registers; against the LDS-resident stepper this spares the eight
+// ds_read_b128 of the observation and the image's round trips (the open loop's REG form: -12 % without a trajectory).
+template <class QA>
+__device__ __forceinline__ void pg_policy_reg_body(const QA &q, const uint32_t base, unsigned char *smem)
+{
+    using Env = PowerGrid;
+    using PL = PgPairLdsT<false, true>;
+    constexpr int S = Env::S, A = Env::A, KS = Env::KS;
+    const float4 *const s_probit = reinterpret_cast<const float4 *>(smem + PgLds<256>::OFF_PROBIT);
+    const nig_policy *const pol = reinterpret_cast<const nig_policy *>(smem + PL::OFF_POL);
+    const v4f *const wd = reinterpret_cast<const v4f *>(smem + PL::OFF_WD);
+    const StepArgs &p = q.s;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    float *const s_img = reinterpret_cast<float *>(smem + PgLds<256>::OFF_IMG) + wave * 2048;      // the cooperative reset's [32][64] image
+    unsigned char *const s_wlist = smem + PgLds<256>::OFF_WLIST + wave * 64;
+    const v4f *const nz_ring = reinterpret_cast<const v4f *>(smem + PL::OFF_NZ) + wave * (PL::K * PL::SLOT_V4);
+    lds_u32_t *const nz_sync = (lds_u32_t *)(smem + PL::OFF_SYNC) + wave * 4;
+    const uint32_t t_base = (p.t_ptr ? *p.t_ptr : 0u) + p.t_off;
+    const bool tally = p.tally != nullptr;
+    uint32_t ctr = (p.ctr + base)[tid];
+    float s[S], n[S], a[A];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = (p.state + base + k * p.ld_state)[tid];
+    double ret = tally ? (p.ep_ret + base)[tid] : 0.0;
+    LaneTally lt;
+    lt.clear();
+    PolicyHead<A> head;
+    head.load(*pol);
+    bool any_sigma, any_half, mix;
+    policy_switches<A>(&head, any_sigma, any_half, mix);
+    float *rew_row = p.reward ? p.reward + base : nullptr;
+    uint32_t *fl_row = p.flags ? p.flags + base : nullptr;
+    float *act_row = q.act_out ? q.act_out + base : nullptr;
+    uint32_t seen = 0u;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int it = 0; it < q.n_steps; ++it) {
+        if (seen < (uint32_t)it + 1u) seen = split_wait(nz_sync + 0, (uint32_t)it + 1u);
+        const v4f *slot = nz_ring + (it & (PL::K - 1)) * PL::SLOT_V4 + lane;
+        float z[24];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const v4f w = slot[64 * j]; z[4 * j] = w.x; z[4 * j + 1] = w.y; z[4 * j + 2] = w.z; z[4 * j + 3] = w.w; }
+        const float *dr = reinterpret_cast<const float *>(nz_ring + (it & (PL::K - 1)) * PL::SLOT_V4 + PL::NZ_V4) + lane;
+        PolicyDraws<A> d;
+        if (any_sigma) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) d.z[k] = dr[k * 64];
+        }
+        if (any_half) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) d.h[k] = dr[(8 + k) * 64];
+        }
+        if (mix) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) d.ra[k] = dr[(16 + k) * 64];
+            d.wmix = dr[24 * 64];
+        }
+        split_post(nz_sync + 1, (uint32_t)it + 1u, lane);          // (DS order: the reads above execute before this write)
+        policy_affine_dense<Env, 4>(head, wd, s, a);       // (four columns ahead: this wave also holds the whole state)
+        policy_finish_sw<Env>(&head, any_sigma, any_half, mix, head.clip_lo, head.clip_hi, d, a);
+        if (act_row) {                             // the policy's action, before the env's own clip
+#pragma unroll
+            for (int j = 0; j < A; ++j) stream_store(act_row + j * q.ld_act_out + tid, a[j]);
+            act_row += q.act_step_stride;
+        }
+        float nz[KS];
+        Env::scale_step_normals(z, nz);
+        const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
+        StepResult<Env> res;
+        step_core<Env>(s, a, nz, step_pre, p.max_steps, p.dt32, p.dt, p.cmask, n, res);
+        const int step = step_pre + 1;
+        const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
+        const bool done = res.terminated || res.truncated;
+        const uint32_t fl = pack_flags<Env>(res, step) | (done ? NIG_FLAG_DID_RESET : 0u);
+        ctr = (uint32_t)step | (viol_ep << NIG_CTR_VIOL_SHIFT);
+        if (tally) ret = ret + (double)res.reward;
+        if (rew_row) { stream_store(rew_row + tid, (float)res.reward); rew_row += q.out_stride; }
+        if (fl_row) { stream_store(fl_row + tid, fl); fl_row += q.out_stride; }
+        if (done) {
+            lt.life += (long long)viol_ep;
+            if (tally) { lt.episode(ret, step, viol_ep, res.ncrit); ret = 0.0; }
+            ctr = 0u;
+        }
+        const unsigned long long m = __ballot(done);
+        if (m != 0ull)
+            coop_reset<Env>(m, done, lane, s_img, s_wlist, p.env0 + (uint64_t)(base + (tid & ~63u)), t_base + (uint32_t)it + 1u,
+                            p.seed_lo, p.seed_hi, s_probit, n);
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = n[k];
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) (p.state + base + k * p.ld_state)[tid] = s[k];
+    (p.ctr + base)[tid] = ctr;
+    if (lt.life != 0) (p.life_viol + base)[tid] += lt.life;
+    if (tally) {
+        (p.ep_ret + base)[tid] = ret;
+        if (lt.episodes > 0) lt.merge(p.tally + base + tid, p.ld, p.n_en);
+    }
+    NIG_RING_REPORT(p.ring_err, nz_sync, lane);
+}
+
 // The paired form of the CLOSED loop (nig_rollout_policy, affine policies): as above, the producers also draw the policy's
 // own random numbers of the step, the stepping waves evaluate the feedback law on their image.  QA = PolicyArgs (a template
 // parameter only because that type is defined after this header); q.block0 counts 256-lane blocks.
@@ -641,7 +744,12 @@ __global__ void __launch_bounds__(512, 2) rollout_pg_pair_policy_kernel(const QA
     const uint32_t base = (blockIdx.x + q.block0) * 256u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= 4u) pg_pair_producer<false, true, QA>(q, base, smem, wave - 4u, threadIdx.x & 63u);
+#ifdef NIG_DIAG_PG_POLICY_LDS          // (diagnostic builds only: the LDS-resident stepper for every call, for same-box A/Bs)
     else pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);
+#else
+    else if (q.obs_out != nullptr) pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);     // its image transposes the observation rows
+    else pg_policy_reg_body<QA>(q, base, smem);
+#endif
 }
 
 template <class E, class = void> struct pair_rollout : std::false_type {};
