@@ -312,7 +312,9 @@ extern "C" {
 // 0.3.0, "nig-philox-v3" (round 4): as v2, except that PowerGrid's eight RESET load factors are 16-bit uniforms taken from the
 // low bytes of the reset normals' words (six Philox blocks per reset instead of eight): PowerGrid trajectories differ from v2's
 // from the first auto-reset on; ChemicalReactor, RobotAssembly and every other env are bit-identical to v2.
-const char *nig_version(void) { return "nig 0.3.0 (gfx950; generator nig-philox-v3)"; }
+// 0.4.0 (round 4): generator unchanged for the reference's envs; the four build-specified plants moved to their model "v2"
+// (spec_plants.py: fused multiply-adds, steps 2k-1 / 2k sharing one generator block) -- their trajectories differ from 0.3.0's.
+const char *nig_version(void) { return "nig 0.4.0 (gfx950; generator nig-philox-v3)"; }
 const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)
@@ -996,7 +998,13 @@ struct nig_mixed {
 // relative cost of one env-step (fused rollout, measured per-env rates): launch order = most expensive first
 static int env_cost(int env)
 {
-    static const int C[NIG_NUM_ENVS] = {10, 44, 50, 15, 20, 14, 9, 17, 29};
+    static int C[NIG_NUM_ENVS] = {10, 44, 50, 15, 20, 14, 9, 17, 29};
+    static int init = 0;
+    if (!init) {                                   // EXPERIMENT (remove): NIG_DIAG_MIXED_COST="c0,c1,...,c8"
+        init = 1;
+        const char *e = getenv("NIG_DIAG_MIXED_COST");
+        if (e) { int k = 0; while (*e && k < NIG_NUM_ENVS) { C[k++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; } }
+    }
     return C[env];
 }
 

@@ -871,11 +871,11 @@ struct SpecPlant {
     static constexpr bool COOP_RESET = false;
     static constexpr bool HAS_ACT64 = false;     // build-specified plants are float32 by design
     static constexpr int RESET_ROWS = 1;
-    using fast_noise_t = double;
+    using fast_noise_t = float;      // step noise is a float32 value (nsd * z): carried as float, widened only where draws are injected
     static constexpr int NP = NIG_SPEC_NP[K], A = NIG_SPEC_NA[K], S = NP + A + 3, ID = 5 + K;
     static constexpr int KS = 2, KR = NP, MAX_STEPS = NIG_SPEC_MAXSTEPS[K];
     static constexpr int ROW_E = NP + A, ROW_ECUM = NP + A + 1, ROW_T = NP + A + 2;
-    static constexpr bool COMPACT_RESET = false, SHARED_STEP_BLOCK = false, CUSTOM_STEP = false, RET_F32 = true;
+    static constexpr bool COMPACT_RESET = false, SHARED_STEP_BLOCK = true, CUSTOM_STEP = false, RET_F32 = true;
     static constexpr int STEP_BLOCK = 256, STEP_WAVES = 4, ROLLOUT_WAVES = (S > 24) ? 2 : 3;
     using reward_t = float;
     __device__ static constexpr float act_low(int) { return -1.0f; }
@@ -901,13 +901,39 @@ struct SpecPlant {
 #pragma unroll
         for (int i = 0; i < NP; ++i) n[i] = 0.0 + (double)P.sd0[i] * (double)z[i];
     }
-    __device__ static void draw_step(const RngKey &k, double (&n)[KS])
+    // Two draws per step: launch counters 2k-1 and 2k share ONE Philox block (counter word k, words 0-1 for the odd
+    // counter, 2-3 for the even one) -- ChemicalReactor's rule, plant model "v2" (0.4.0) on: half of every block used to be thrown
+    // away, and a block is 12 of the step's ~45 slow (64-bit multiply) issue slots.
+    __device__ static u32x4 step_block(const RngKey &k)
+    {
+        RngKey kk = k;
+        kk.t = (k.t + 1u) >> 1;
+        return kk.block(STREAM_STEP);
+    }
+    __device__ static void step_noise_fetch(uint32_t w0, uint32_t w1, const float4 *tab, ProbitFetch (&f)[KS])
+    {
+        f[0] = probit_fetch(w0, tab); f[1] = probit_fetch(w1, tab);
+    }
+    template <class NZ>
+    __device__ static void step_noise_eval(const ProbitFetch (&f)[KS], NZ (&n)[KS])
     {
         constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
-        float z[KS];
-        gen_normals<KS>(k, STREAM_STEP, z);
-        n[0] = (double)(P.nsd[0] * z[0]);
-        n[1] = (double)(P.nsd[1] * z[1]);
+        n[0] = (NZ)(P.nsd[0] * probit_eval(f[0]));
+        n[1] = (NZ)(P.nsd[1] * probit_eval(f[1]));
+    }
+    template <class NZ>
+    __device__ static void step_noise(uint32_t w0, uint32_t w1, const float4 *tab, NZ (&n)[KS])
+    {
+        ProbitFetch f[KS];
+        step_noise_fetch(w0, w1, tab, f);
+        step_noise_eval(f, n);
+    }
+    template <class NZ>
+    __device__ static void draw_step(const RngKey &k, NZ (&n)[KS])
+    {
+        const u32x4 x = step_block(k);
+        const bool second = (k.t & 1u) == 0;
+        step_noise(second ? x.z : x.x, second ? x.w : x.y, k.tab, n);
     }
 
     // The plant model's clip(v, lo, hi) (spec_plants.py): the larger of v and lo, then the smaller of that and hi; a NaN
@@ -945,31 +971,34 @@ struct SpecPlant {
         return (P.clo[c] <= mn) & (mx <= P.chi[c]);
     }
 
-    __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const double (&nz)[KS],
+    template <class NZ>
+    __device__ static void dynamics(const float (&s)[S], const float (&a)[A], const NZ (&nz)[KS],
                                     float dt32, double, float (&o)[S])
     {
         constexpr spec_plant_t P = NIG_SPEC_PLANTS[K];
+        // (model arithmetic, spec_plants.py "v2": every multiply-add below is ONE fused operation with one rounding --
+        // v_fma_f32 here, fmaf() in the CPU statement)
         float pn[A];
         float e = 0.0f;
 #pragma unroll
         for (int j = 0; j < A; ++j) {              // velocity-form actuators, clipped to [0, 1]
-            pn[j] = clamp(s[NP + j] + (P.rate[j] * a[j]) * dt32, 0.0f, 1.0f);
-            e = e + P.ecost[j] * pn[j];
+            pn[j] = clamp(__builtin_fmaf(P.rate[j] * a[j], dt32, s[NP + j]), 0.0f, 1.0f);
+            e = __builtin_fmaf(P.ecost[j], pn[j], e);
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             float dy = (-P.k[i]) * (s[i] - P.amb[i]);
 #pragma unroll
             for (int j = 0; j < A; ++j)
-                if (P.G[i][j] != 0.0f) dy = dy + P.G[i][j] * pn[j];
-            if (P.cpl[i] != 0.0f) dy = dy + P.cpl[i] * (s[P.cidx[i]] - s[i]);
+                if (P.G[i][j] != 0.0f) dy = __builtin_fmaf(P.G[i][j], pn[j], dy);
+            if (P.cpl[i] != 0.0f) dy = __builtin_fmaf(P.cpl[i], s[P.cidx[i]] - s[i], dy);
             if (i < KS) dy = dy + (float)nz[i];
-            o[i] = clamp(s[i] + dy * dt32, P.ymin[i], P.ymax[i]);
+            o[i] = clamp(__builtin_fmaf(dy, dt32, s[i]), P.ymin[i], P.ymax[i]);
         }
 #pragma unroll
         for (int j = 0; j < A; ++j) o[NP + j] = pn[j];
         o[ROW_E] = e;
-        o[ROW_ECUM] = s[ROW_ECUM] + e * dt32;
+        o[ROW_ECUM] = __builtin_fmaf(e, dt32, s[ROW_ECUM]);
         o[ROW_T] = s[ROW_T] + dt32;
     }
 
@@ -979,12 +1008,12 @@ struct SpecPlant {
         float r = 0.0f;
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            if (P.w[i] != 0.0f) r = r - P.w[i] * fabsf(n[i] - P.sp[i]);
-        r = r - P.we * n[ROW_E];
+            if (P.w[i] != 0.0f) r = __builtin_fmaf(-P.w[i], fabsf(n[i] - P.sp[i]), r);
+        r = __builtin_fmaf(-P.we, n[ROW_E], r);
         float ap = 0.0f;
 #pragma unroll
         for (int j = 0; j < A; ++j) ap = ap + fabsf(a[j]);
-        r = r - P.wu * ap;
+        r = __builtin_fmaf(-P.wu, ap, r);
         return box_ok(n, 0) ? (r + P.bonus) : r;   // bonus while constraint 0 holds on the new state
     }
 

@@ -46,14 +46,24 @@ __global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs
     // A WHOLE block of a handle on which no lane can be frozen runs the unpredicated body without freeze handling (FULL,
     // NOFREEZE: counted vmcnt waits instead of a drain per step, no second copy of the state -- what the stand-alone
     // kernels' whole blocks run); a segment's ragged last block, or a handle with frozen lanes, the predicated one.
-    // ChemicalReactor stays unpaired (its launch-counter parity is per handle).
     const bool lean = base + BLOCK <= q.s.B && (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+    // The envs whose steps 2k-1, 2k share one generator block (ChemicalReactor, the four plants): whole blocks of a
+    // segment whose FIRST step has an odd launch counter run the paired body -- one Philox block per two steps, the
+    // normals produced a step ahead (rollout_body PAIRED; the stand-alone launches peel a misaligned first step on the
+    // host, here a segment that starts on an even counter simply runs the unpaired body: same values either way).
+    const uint32_t t_first = (q.s.t_ptr ? *q.s.t_ptr : 0u) + q.s.t_off + (uint32_t)q.it0 + 1u;     // block-uniform
+    const bool paired = lean && (t_first & 1u) != 0u;
 #define NIG_MIXED_BODY(Env)                                                   \
     if (lean) rollout_body<Env, OUT, false, true, true>(q, base, smem);        \
     else rollout_body<Env, OUT, false, false>(q, base, smem);                  \
     break
+#define NIG_MIXED_BODY_SHARED(Env)                                            \
+    if (paired) rollout_body<Env, OUT, true, true, true>(q, base, smem);       \
+    else if (lean) rollout_body<Env, OUT, false, true, true>(q, base, smem);   \
+    else rollout_body<Env, OUT, false, false>(q, base, smem);                  \
+    break
     switch (env) {
-    case NIG_ENV_CHEMICAL_REACTOR: NIG_MIXED_BODY(ChemicalReactor);
+    case NIG_ENV_CHEMICAL_REACTOR: NIG_MIXED_BODY_SHARED(ChemicalReactor);
     case NIG_ENV_POWER_GRID:
         // whole blocks: the LDS-resident body (nig_pg_lds.hpp; ~110 registers, where the register-resident one spilled ~70
         // dwords under this kernel's 168) -- bit-identical, tests/test_gpu_mixed.py
@@ -63,12 +73,13 @@ __global__ void __launch_bounds__(BLOCK, 3) mixed_rollout_kernel(const MixedArgs
     case NIG_ENV_ROBOT_ASSEMBLY: NIG_MIXED_BODY(RobotAssembly);
     case NIG_ENV_ADV_CHEMICAL_REACTOR: NIG_MIXED_BODY(AdvancedChemicalReactor);
     case NIG_ENV_ADV_POWER_GRID: NIG_MIXED_BODY(AdvancedPowerGrid);
-    case NIG_ENV_HVAC_CONTROL: NIG_MIXED_BODY(HVACControl);
-    case NIG_ENV_WATER_TREATMENT: NIG_MIXED_BODY(WaterTreatment);
-    case NIG_ENV_STEEL_ANNEALING: NIG_MIXED_BODY(SteelAnnealing);
-    default: NIG_MIXED_BODY(SupplyChain);
+    case NIG_ENV_HVAC_CONTROL: NIG_MIXED_BODY_SHARED(HVACControl);
+    case NIG_ENV_WATER_TREATMENT: NIG_MIXED_BODY_SHARED(WaterTreatment);
+    case NIG_ENV_STEEL_ANNEALING: NIG_MIXED_BODY_SHARED(SteelAnnealing);
+    default: NIG_MIXED_BODY_SHARED(SupplyChain);
     }
 #undef NIG_MIXED_BODY
+#undef NIG_MIXED_BODY_SHARED
 }
 
 }  // namespace nig

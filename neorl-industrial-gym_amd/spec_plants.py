@@ -21,7 +21,20 @@ clip(v, lo, hi) = min(max(v, lo), hi) on float32 with a NaN mapped to lo (IEEE m
 the device, two compares in the CPU statement).
 
 State layout: [y_0..y_NP-1, p_0..p_A-1, e, E, t], all float32, evaluated in exactly this order
-with one rounding per operation (csrc/nig_envs.hpp SpecPlant<K>; the tests' CPU restatement mirrors it).
+(csrc/nig_envs.hpp SpecPlant<K>; the tests' CPU restatement mirrors it).  Model arithmetic "v2" (0.4.0 on): a product
+that is added to a running value is ONE fused multiply-add with one rounding -- the native operation of the device
+(v_fma_f32) and fmaf() in the CPU statement -- everything else rounds once per operation:
+
+    p_j'  = clip(fma(rate_j * a_j, dt, p_j), 0, 1);        e' = fma(ecost_j, p_j', e') over j, from 0
+    dy_i  = (-k_i) * (y_i - amb_i); dy_i = fma(G_ij, p_j', dy_i) over the non-zero gains in j order;
+            dy_i = fma(cpl_i, y_cidx_i - y_i, dy_i); dy_i = dy_i + noise_i (i < 2)
+    y_i'  = clip(fma(dy_i, dt, y_i), ymin_i, ymax_i);      E' = fma(e', dt, E)
+    reward: r = fma(-w_i, |y_i' - sp_i|, r) over the weighted rows from 0; r = fma(-we, e', r); r = fma(-wu, sum_j |a_j|, r)
+
+and the two step-noise draws of launch counters 2k-1 and 2k come from ONE generator block (counter word k: words 0-1 for the odd
+counter, 2-3 for the even one -- ChemicalReactor's rule; v1 drew a block per step and threw half of it away).
+("v1", up to 0.3.0, rounded the product and the sum separately: twice the instructions on a device whose multiply-add is
+one instruction, and no CPU without an FMA unit is a target of the statement.)
 Each safety constraint is a box over a run of state rows.
 
 This file is the single source of the numbers: `python spec_plants.py` regenerates
