@@ -147,8 +147,9 @@ const char *nig_last_error(void);
  *                           NIG_SPLIT_BLOCKS sets the initial value.
  *   NIG_TUNE_WIDE_MIN_BLOCKS  smallest batch, in 512-lane blocks, that nig_rollout runs in the WIDE form (csrc/nig_kernels.hpp
  *                           rollout_wide_kernel: PowerGrid, 512-thread blocks at four waves per SIMD,
- *                           handles on which no lane can be frozen); default = the compute units of the handle's
- *                           device (one wide block per compute unit); smaller batches run the same LDS-resident
+ *                           handles on which no lane can be frozen); default = 1.5 x the compute units of the handle's
+ *                           device + 1 (the first batch that no longer fits one round of the 256-lane form at three
+ *                           blocks per compute unit); smaller batches run the same LDS-resident
  *                           body in 256-lane blocks; 2^30 or more = never use that body (rollout_kernel only).  Environment variable NIG_WIDE_MIN_BLOCKS sets the initial value.
  * A value of -1 removes an explicit setting: every handle is back on its own device's default (tests restore with it).
  * nig_tune returns NIG_OK or NIG_ERR_INVALID (unknown key / value below -1); nig_tune_get returns the value in effect

@@ -300,8 +300,12 @@ unsigned split_blocks_for(unsigned cus)
 }
 unsigned wide_min_blocks_for(unsigned cus)
 {
+    // default: the wide form (two 512-lane blocks per CU, four waves per SIMD) from the first batch that no longer fits ONE round of
+    // the 256-lane form (three blocks per CU): a round of either takes a time proportional to its waves per SIMD (4 : 3), so up to
+    // 1.5 wide blocks per CU the 256-lane form's single round wins -- 196 608 lanes x 250 steps, reward + flags: 1.23 ms against
+    // 1.54 ms wide; 262 144 lanes (config 3): wide 1.57 ms against 1.67 ms (profiles/r04/pg_forms.txt).  Up to round 3: `cus`.
     const unsigned o = g_wide_override.load(std::memory_order_relaxed);
-    return o != TUNE_UNSET ? o : cus;
+    return o != TUNE_UNSET ? o : cus + cus / 2 + 1;
 }
 }
 
@@ -995,16 +999,12 @@ struct nig_mixed {
     float *state;              // [s_max][ld], owned
 };
 
-// relative cost of one env-step (fused rollout, measured per-env rates): launch order = most expensive first
+// relative cost of one env-step (fused rollout, measured per-env rates): launch order = most expensive first.  (Round 4,
+// profiles/r04/mixed_order.txt: PowerGrid before RobotAssembly or after makes no difference, 2.69 vs 2.70 ms; the cheap
+// envs first costs +10 %, RobotAssembly last +13 %.)
 static int env_cost(int env)
 {
-    static int C[NIG_NUM_ENVS] = {10, 44, 50, 15, 20, 14, 9, 17, 29};
-    static int init = 0;
-    if (!init) {                                   // EXPERIMENT (remove): NIG_DIAG_MIXED_COST="c0,c1,...,c8"
-        init = 1;
-        const char *e = getenv("NIG_DIAG_MIXED_COST");
-        if (e) { int k = 0; while (*e && k < NIG_NUM_ENVS) { C[k++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; } }
-    }
+    static const int C[NIG_NUM_ENVS] = {10, 44, 50, 15, 20, 14, 9, 17, 29};
     return C[env];
 }
 

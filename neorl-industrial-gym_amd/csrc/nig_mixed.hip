@@ -9,6 +9,7 @@
 // The price of one kernel for all envs: every block runs under ONE register allocation.  It is set for three waves
 // per SIMD (168 registers; LDS, 45 KB per block, allows three).  PowerGrid's register-resident body wants ~185 and
 // spilled ~70 dwords here (round 2); since round 3 its whole blocks run the LDS-resident body (nig_pg_lds.hpp, ~110).
+// Round 4: ChemicalReactor and the four plants run their PAIRED bodies when the segment starts on an odd launch counter.
 #include "nig_kernels.hpp"
 
 namespace nig {

@@ -14,6 +14,8 @@ template <int OP>
 __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
 {
     uint32_t a[8]; float f[8]; double d[8]; uint64_t q[8];
+    const float fs = __builtin_bit_cast(float, 0x3f800001u + (seed & 1u));          // wave-uniform: lives in a scalar register
+    const uint64_t msk = 0x5555555555555555ull + seed;
     for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 8 + i; f[i] = (float)a[i] * 1e-3f; d[i] = (double)f[i]; q[i] = a[i]; }
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -52,6 +54,33 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
             if constexpr (OP == 37) asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
             if constexpr (OP == 38) asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]), "v"(a[(i + 3) & 7]));
             if constexpr (OP == 39) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(d[i]));
+            // round 4: operand kinds -- does a scalar register, a 32-bit literal or an inline constant as a source change the rate?
+            if constexpr (OP == 40) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(f[i]) : "s"(fs));                       // VOP2, SGPR src0
+            if constexpr (OP == 41) asm volatile("v_mul_f32 %0, 0x3ecccccd, %0" : "+v"(f[i]));                          // VOP2, literal
+            if constexpr (OP == 42) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(f[i]));                                 // VOP2, inline constant
+            if constexpr (OP == 43) asm volatile("v_fmac_f32 %0, 0x3ecccccd, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));  // VOP2 fmac, literal
+            if constexpr (OP == 44) asm volatile("v_fmac_f32 %0, %2, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]), "s"(fs)); // VOP2 fmac, SGPR
+            if constexpr (OP == 45) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i]) : "v"(f[(i + 1) & 7]), "s"(fs));   // VOP3 fma, SGPR
+            if constexpr (OP == 46) asm volatile("v_add_f32 %0, 0x42f60000, %0" : "+v"(f[i]));                          // VOP2 add, literal
+            if constexpr (OP == 47) asm volatile("v_and_b32 %0, 0x3fff0, %0" : "+v"(a[i]));                             // VOP2 and, literal
+            if constexpr (OP == 48) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));   // all VGPR
+            if constexpr (OP == 49) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q[i]) : "v"(a[(i + 1) & 7]), "v"(a[i]) : "vcc");            // all VGPR
+            if constexpr (OP == 51) asm volatile("v_maximum3_f32 %0, %0, %1, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if constexpr (OP == 52) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if constexpr (OP == 53) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(msk));                        // VOP3, SGPR-pair mask
+            if constexpr (OP == 54) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if constexpr (OP == 55) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if constexpr (OP == 56) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if constexpr (OP == 57) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if constexpr (OP == 58) asm volatile("v_add_f32 %0, 0.5, %0" : "+v"(f[i]));                                 // inline constant
+            if constexpr (OP == 60) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(f[i]) : "v"(a[i]));
+            if constexpr (OP == 61) asm volatile("v_alignbit_b32 %0, %1, %2, 8" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if constexpr (OP == 62) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]), "v"(a[(i + 3) & 7]));
+            if constexpr (OP == 63) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if constexpr (OP == 64) asm volatile("v_ashrrev_i32 %0, 3, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if constexpr (OP == 65) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if constexpr (OP == 66) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if constexpr (OP == 67) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
             // dependent chain of the wide multiply (Philox round structure: mad -> use hi)
             if constexpr (OP == 13) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q[0]) : "s"(0xD2511F53u), "v"(a[0]) : "vcc"); a[0] = (uint32_t)(q[0] >> 32); }
             if constexpr (OP == 14) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f[0]) : "v"(f[1]));   // dependent fma chain
@@ -107,6 +136,7 @@ int main()
         CHECK(hipMemcpy(h, cp, 16, hipMemcpyDeviceToHost));
         printf("in-kernel clock under an all-CU VALU load: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)\n", (double)h[0] / (double)h[1] * 100.0);
     }
+    if (!getenv("VALU_RATE_NEW_ONLY")) {
     run<0>("v_fma_f32 (indep)", ncu, mhz, out);
     run<14>("v_fma_f32 (dependent)", ncu, mhz, out);
     run<1>("v_mad_u64_u32 (indep)", ncu, mhz, out);
@@ -142,5 +172,35 @@ int main()
     run<35>("v_pk_mul_f32", ncu, mhz, out);
     run<36>("v_pk_add_f32", ncu, mhz, out);
     run<39>("v_cvt_f32_f64", ncu, mhz, out);
+    }
+    if (getenv("VALU_RATE_OLD_ONLY")) return 0;
+    printf("-- round 4: operand kinds\n");
+    run<21>("v_mul_f32 v,v (anchor)", ncu, mhz, out);
+    run<40>("v_mul_f32 v,s", ncu, mhz, out);
+    run<41>("v_mul_f32 v,literal", ncu, mhz, out);
+    run<42>("v_mul_f32 v,inline 0.5", ncu, mhz, out);
+    run<43>("v_fmac_f32 literal", ncu, mhz, out);
+    run<44>("v_fmac_f32 sgpr", ncu, mhz, out);
+    run<45>("v_fma_f32 sgpr", ncu, mhz, out);
+    run<46>("v_add_f32 literal", ncu, mhz, out);
+    run<58>("v_add_f32 inline", ncu, mhz, out);
+    run<54>("v_sub_f32", ncu, mhz, out);
+    run<47>("v_and_b32 literal", ncu, mhz, out);
+    run<48>("v_bitop3_b32 v,v,v", ncu, mhz, out);
+    run<49>("v_mad_u64_u32 v,v", ncu, mhz, out);
+    run<51>("v_maximum3_f32", ncu, mhz, out);
+    run<52>("v_min_f32", ncu, mhz, out);
+    run<53>("v_cndmask_b32 sgpr mask", ncu, mhz, out);
+    run<55>("v_lshlrev_b32", ncu, mhz, out);
+    run<64>("v_ashrrev_i32", ncu, mhz, out);
+    run<56>("v_or_b32", ncu, mhz, out);
+    run<57>("v_and_or_b32", ncu, mhz, out);
+    run<63>("v_sub_u32", ncu, mhz, out);
+    run<60>("v_cvt_f32_ubyte0", ncu, mhz, out);
+    run<61>("v_alignbit_b32", ncu, mhz, out);
+    run<62>("v_perm_b32", ncu, mhz, out);
+    run<65>("v_mul_u32_u24", ncu, mhz, out);
+    run<66>("v_mad_u32_u24", ncu, mhz, out);
+    run<67>("v_mul_hi_u32_u24", ncu, mhz, out);
     return 0;
 }
