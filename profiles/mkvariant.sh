@@ -13,7 +13,7 @@ for tu in $tus; do
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -w $extra -c -o /tmp/${tu}_$name.o $P/csrc/$tu.hip &
   pids+=($!)
   objs=$(echo "$objs" | grep -v "/$tu.o")
-  objs="$objs /tmp/${tu}_$name.o"
+  objs="$objs"$'\n'"/tmp/${tu}_$name.o"     # (one object per line: the grep above works line by line)
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libnig_$name.so $objs -ldl
