@@ -67,6 +67,12 @@ def test_tune_knob_needs_no_gpu():
     assert L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == 12
     # -1 = no explicit setting: back to the per-device default
     assert L.nig_tune(_lib.TUNE_SPLIT_BLOCKS, -1) == 0 and L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS) == before
+    # per-device defaults (no handle yet: a 256-CU device is assumed): one 256-lane block per compute unit for the three-wave /
+    # paired forms; the wide form from the first batch that no longer fits one round of the 256-lane form (1.5 blocks per CU)
+    if "NIG_SPLIT_BLOCKS" not in os.environ and "NIG_WIDE_MIN_BLOCKS" not in os.environ:
+        assert L.nig_tune(_lib.TUNE_WIDE_MIN_BLOCKS, -1) == 0
+        cus = L.nig_tune_get(_lib.TUNE_SPLIT_BLOCKS)
+        assert L.nig_tune_get(_lib.TUNE_WIDE_MIN_BLOCKS) == cus + cus // 2 + 1
 
 
 def test_layout_query():
