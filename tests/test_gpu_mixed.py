@@ -195,6 +195,10 @@ def test_rollout_mixed_over_caller_owned_handles(ni):
     a.rollout(T, ring, ra, fa, oa); b.rollout(T, ring, rb, fb, ob)
     a.rollout(7, ring); b.rollout(7, ring)                      # output-free form, odd length
     a.rollout(5, ring, ra[:5], fa[:5]); b.rollout(5, ring, rb[:5], fb[:5])      # reward + flags only
+    # short launches: the paired bodies (ChemicalReactor, the plants: four steps per loop pass) and the two-step ones run their
+    # tails only; the launch counter alternates between odd and even starts (paired / unpaired body of the same segment)
+    for n in (1, 2, 3, 4, 1, 3):
+        a.rollout(n, ring, ra[:n], fa[:n]); b.rollout(n, ring, rb[:n], fb[:n])
     torch.cuda.synchronize()
     assert torch.equal(a.state_soa.view(torch.int32), b.state_soa.view(torch.int32))
     assert torch.equal(ra, rb) and torch.equal(fa, fb)
@@ -205,7 +209,7 @@ def test_rollout_mixed_over_caller_owned_handles(ni):
         assert not bool(torch.isnan(oa[:, :env.state_dim, o:o + env.batch]).any())
         assert bool(torch.isnan(oa[:, env.state_dim:, o:o + env.batch]).all()) or env.state_dim == a.S_max
     for x, y in zip(a.envs, b.envs):
-        assert torch.equal(x.ctr, y.ctr) and torch.equal(x.tally, y.tally) and x.counter == y.counter == T + 7 + 5
+        assert torch.equal(x.ctr, y.ctr) and torch.equal(x.tally, y.tally) and x.counter == y.counter == T + 7 + 5 + 14
     a.close(); b.close()
 
 
