@@ -448,7 +448,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 };
                 auto walk_flow = [&](float h, int c) __attribute__((always_inline)) -> float {
                     if constexpr (NOISE) return (float)((double)h + zd[c]);
-                    else return h + 2.0f * zn(c);
+                    else return __builtin_fmaf(2.0f, zn(c), h);       // == h + 2.0f * z: the product is exact, one rounding either way
                 };
                 asm volatile("" ::: "memory");                               // the groups are read again HERE, not kept from the top
                 __builtin_amdgcn_sched_barrier(0);
