@@ -29,7 +29,9 @@ Modes (same arithmetic, bit-identical results -- tests/test_gpu_parity.py):
                      --plan-steps of them replayed from one hipGraph / launched one by one.
 
 One JSON line on rank 0: metric/value/... + "roofline" + "cpu_baseline" (+ "parity", "step_api",
-"powergrid" = BASELINE configs[2] per GPU, i.e. configs[4] when N = 8).
+"powergrid" = BASELINE configs[2] per GPU, i.e. configs[4] when N = 8, "robotassembly" = the third reference env at the
+same batch, "mixed" = configs[3], "single_env" = configs[0]); every timed record carries `rank_times.clock` (the shader clock
+held over the timed launches, in-kernel counters) and `rank_times.dpm` (sclk / mclk / power while its settle launches ran).
 """
 import argparse
 import json
@@ -145,7 +147,104 @@ class Workload:
         self.env.close()
 
 
-def settle(torch, wl, seconds):
+class ClockProbe:
+    """The clock the chip HELD over a run of launches (box-to-box spread of 164-176 us on an unchanged
+    kernel could not be attributed): two nig_clock_stamp launches around the run, each writing s_memtime (shader-clock counter)
+    and s_memrealtime (constant 100 MHz) per XCD; shader clock = d memtime / d memrealtime x 100 MHz.  The stamps are tiny
+    kernels OUTSIDE the timed interval (before its opening barrier, after its clock has stopped)."""
+
+    def __init__(self, ni, torch, device):
+        self.L, self.torch = ni._lib.lib(), torch
+        self.buf = torch.zeros(2, 16, dtype=torch.int64, device=device)
+
+    def stamp(self, i):
+        self.L.nig_clock_stamp(self.torch.cuda.current_stream().cuda_stream, self.buf[i].data_ptr())
+
+    def read(self):
+        import numpy as np
+        v = self.buf.cpu().numpy().astype(np.uint64).reshape(2, 8, 2)
+        mhz, span = [], []
+        for x in range(8):
+            (t0, r0), (t1, r1) = v[0, x], v[1, x]
+            if t0 and t1 and r1 > r0 and t1 > t0:
+                mhz.append(float(t1 - t0) / float(r1 - r0) * 100.0)
+                span.append(float(r1 - r0) / 1e5)
+        if not mhz:
+            return {"error": "no XCD stamped twice"}
+        mhz_sorted = sorted(mhz)
+        return {"shader_clock_mhz": mhz_sorted[len(mhz_sorted) // 2], "shader_clock_mhz_min": mhz_sorted[0], "shader_clock_mhz_max": mhz_sorted[-1],
+                "xcds": len(mhz), "span_ms": sorted(span)[len(span) // 2],
+                "how": "(s_memtime1 - s_memtime0) / (s_memrealtime1 - s_memrealtime0) x 100 MHz per XCD, median; stamps outside the timed interval"}
+
+
+_PROBE = None            # set by main() on a GPU run
+_DPM_DIR = None
+
+
+def gpu_sysfs_dir(torch, idx):
+    """sysfs directory of HIP device `idx` (its PCI function), for the DPM state files rocm-smi reads."""
+    import glob
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        if os.path.exists(d + "/pp_dpm_sclk"):
+            return d
+    except Exception:
+        pass
+    try:
+        amd = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+               if open(c + "/vendor").read().strip() == "0x1002" and os.path.exists(c + "/pp_dpm_sclk")]
+        return amd[idx] if idx < len(amd) else None
+    except Exception:
+        return None
+
+
+def dpm_sample(d):
+    """What `rocm-smi --showclocks --showpower` would print at this moment, read from the files it reads (no child process
+    while launches are in flight): the starred level of pp_dpm_sclk / pp_dpm_mclk, hwmon power, gpu_busy_percent."""
+    import glob
+    if not d:
+        return {"error": "no sysfs directory for this device"}
+    out = {}
+
+    def starred(name):
+        try:
+            for line in open(f"{d}/{name}"):
+                if "*" in line:
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
+    out["sclk_mhz"], out["mclk_mhz"] = starred("pp_dpm_sclk"), starred("pp_dpm_mclk")
+    for name in ("power1_average", "power1_input"):
+        f = glob.glob(f"{d}/hwmon/hwmon*/{name}")
+        if f:
+            try:
+                out["power_w"] = int(open(f[0]).read()) / 1e6
+                break
+            except Exception:
+                pass
+    try:
+        out["gpu_busy_percent"] = int(open(f"{d}/gpu_busy_percent").read())
+    except Exception:
+        pass
+    out["how"] = "sysfs pp_dpm_sclk / pp_dpm_mclk (starred level), hwmon power, read while the settle phase's launches were in flight"
+    return out
+
+
+def grouped(dist, world=1):
+    """True when this process is a member of a torch.distributed group: every N > 1 run, and the one-rank "nccl" group of
+    NIG_BENCH_FORCE_PG=1 (the RCCL code path of this file -- init_process_group("nccl"), barrier,
+    all_gather of device tensors, all_gather_object, destroy_process_group -- executed on the one GPU a build box has)."""
+    if world > 1:
+        return True
+    try:
+        return bool(dist is not None and dist.is_available() and dist.is_initialized())
+    except AttributeError:               # (a test double without the query functions)
+        return False
+
+
+def settle(torch, wl, seconds, stats=None):
     """Untimed: run the workload back to back for `seconds` before the W warm-up launches.  After an idle phase
     (process start, buffer setup) this GPU takes ~0.1-0.2 s of sustained load to reach its steady state: the first
     20 launches of the headline rollout take 235 us each, launches 1000+ take 175 us (profiles/r02/runlength_probe.txt).
@@ -160,6 +259,8 @@ def settle(torch, wl, seconds):
         while time.perf_counter() < t_end:
             for _ in range(per):
                 wl.launch()
+            if stats is not None and _DPM_DIR:      # launches in flight: the DPM state of THIS load (the last sample is kept)
+                stats["dpm"] = dpm_sample(_DPM_DIR)
             torch.cuda.synchronize()
             n += per
     return n
@@ -177,16 +278,19 @@ def timed(torch, dist, world, comm_dev, wl, K, W, settle_s=0.0, stats=None):
     rank's own wall / device time: wall_min / wall_median / wall_max (s), launch_us per rank (HIP events)."""
     gpu = torch.cuda.is_available()          # False only in the CPU control-flow rehearsal (NIG_BENCH_REHEARSE=cpu)
     sync = torch.cuda.synchronize if gpu else (lambda: None)
-    n_settle = settle(torch, wl, settle_s) if gpu else 0
+    n_settle = settle(torch, wl, settle_s, stats) if gpu else 0
     for _ in range(W):
         wl.launch()
     sync()
     if stats is not None:      # launches of this workload so far, in order: profiles/phase_stats.py splits a kernel trace by them
         stats["phases"] = [{"name": "settle", "launches": n_settle}, {"name": "warmup", "launches": W}, {"name": "timed", "launches": K}]
     ev0 = ev1 = None
+    probe = _PROBE if (gpu and stats is not None) else None
     if gpu:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if probe:
+        probe.stamp(0)
+    if grouped(dist, world):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
@@ -198,10 +302,14 @@ def timed(torch, dist, world, comm_dev, wl, K, W, settle_s=0.0, stats=None):
         ev1.record()
     sync()
     wall = time.perf_counter() - t0          # <- the timed interval ends here, at every world size
-    if world > 1:
+    if probe:
+        probe.stamp(1)
+        sync()
+        stats["clock"] = probe.read()
+    if grouped(dist, world):
         dist.barrier()
     mine = torch.tensor([wall, ev0.elapsed_time(ev1) if gpu else wall * 1e3], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if grouped(dist, world):
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         every = torch.stack(every).cpu()
@@ -383,6 +491,52 @@ def parity_probe_cpu(g, key, B):
             "episodes_gpu": g["episodes"], "episodes_cpu": int(tot.episodes), "state_bits_equal": same}
 
 
+def fast_mode_statistics(ni, key, total, B=0, episodes_per_lane=0, device=None):
+    """The metric's second half -- "safety-violation-count parity" -- in the mode this line times: the
+    workload's episode statistics beside the REFERENCE's for the same loop (tests/golden/reference_stats.npz:
+    performance_benchmark.py:106-133 under uniform float32 actions, run by the reference with its own np.random draws; a
+    committed fixture written by `oracle/gen_golden.py stats`).  Two build-side samples:
+      sample -- ni.uniform_action_statistics: the same fused kernel, generator and auto-reset, a FRESH action every step, the
+                first `episodes_per_lane` episodes of every lane (unbiased); run here, untimed, after the timed regions.  This
+                is the sample tests/test_gpu_reference_stats.py asserts within 4 standard errors (with >= 1e6 episodes).
+      timed_workload -- the device tally of the timed run itself: every episode that FINISHED inside it, under the
+                pre-filled --ring-slot action ring of SURVEY 8(d) (a lane's actions repeat every --ring steps, which is not the
+                reference's loop: ChemicalReactor's violations per episode come out ~3 % lower).  Reported for completeness.
+    deviation_sigma = (build - reference) / the reference's standard error."""
+    import numpy as np
+    L = ni._lib
+    try:
+        d = np.load(os.path.join(ROOT, "tests", "golden", "reference_stats.npz"))
+        ref = {k: d[f"{key}_{k}"].astype(np.float64) for k in ("length", "viol", "crit", "ret")}
+    except Exception as e:
+        return {"error": repr(e)}
+    n_ref = int(ref["length"].size)
+    name = {"length": "episode_length_mean", "viol": "violations_per_episode", "crit": "critical_violations_per_episode", "ret": "return_mean"}
+
+    def table(got, n):
+        out = {"episodes": int(n)}
+        for k, nm in name.items():
+            se = float(ref[k].std() / np.sqrt(n_ref)) or float(np.sqrt(3.0 / n_ref))
+            out[nm] = got[k]
+            out[nm + "_deviation_sigma"] = (got[k] - float(ref[k].mean())) / se
+        return out
+    out = {"reference": dict({"episodes": n_ref, "source": "tests/golden/reference_stats.npz (the reference's own code and draws)"},
+                             **{nm: float(ref[k].mean()) for k, nm in name.items()},
+                             **{nm + "_standard_error": float(ref[k].std() / np.sqrt(n_ref)) for k, nm in name.items()})}
+    n = float(total[L.T_EPISODES])
+    if n > 0:
+        out["timed_workload"] = table({"length": float(total[L.T_LEN_SUM]) / n, "viol": float(total[L.T_VIOL]) / n,
+                                       "crit": float(total[L.T_CRIT]) / n, "ret": float(total[L.T_RET_SUM]) / n}, n)
+    if episodes_per_lane > 0:
+        s = ni.uniform_action_statistics(ENVS[key], B, episodes_per_lane, device=device, outputs="full")
+        m = s["episodes"]
+        out["sample"] = dict(table({"length": s["steps"] / m, "viol": s["viol"] / m, "crit": s["crit"] / m, "ret": s["ret"] / m}, m),
+                             lanes=B, episodes_per_lane=episodes_per_lane, launches=s["launches"])
+        out["violations_per_episode_gpu"], out["violations_per_episode_reference"] = s["viol"] / m, float(ref["viol"].mean())
+        out["within_4_sigma"] = all(abs(v) <= 4.0 for k_, v in out["sample"].items() if k_.endswith("_deviation_sigma"))
+    return out
+
+
 def cpu_baseline(key, B, seconds, seed=0x5EED):
     """oracle/nig_oracle.c (the parity-checked C restatement, libm math) timed on this host: all cores
     and one thread, each on a bounded sample of the SAME workload (same lanes, seeds, policy, auto-reset)."""
@@ -447,6 +601,13 @@ def _cpulist(text):
     return out
 
 
+def numa_cpulists(allowed):
+    """The allowed CPUs of every NUMA node of this host, in node order (sysfs); nodes without an allowed CPU dropped."""
+    nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+    per = [[c for c in _cpulist(open(f"/sys/devices/system/node/node{n}/cpulist").read()) if c in allowed] for n in nodes]
+    return [c for c in per if c]
+
+
 def pin_rank(local_rank, local_world):
     """One rank per GPU: keep this rank's host threads (launch loop, RCCL proxy) on the CPUs of ITS GPU's NUMA node,
     shared evenly with the other ranks of that node; without topology information, an even contiguous share of the
@@ -471,9 +632,7 @@ def pin_rank(local_rank, local_world):
             # usual two-socket node), each rank an even share of ITS node's CPUs -- a node's cpulist holds its cores and their
             # SMT siblings, which a plain split of the CPU numbers would hand to different sockets' ranks
             try:
-                nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
-                per = [[c for c in _cpulist(open(f"/sys/devices/system/node/node{n}/cpulist").read()) if c in set(allowed)] for n in nodes]
-                per = [c for c in per if c]
+                per = numa_cpulists(set(allowed))
                 if len(per) > 1 and local_world % len(per) == 0:
                     rpn = local_world // len(per)                   # ranks per node
                     cpus = per[local_rank // rpn]
@@ -492,12 +651,19 @@ def pin_rank(local_rank, local_world):
         return {"pinned": False, "reason": repr(e)}
 
 
-def scale_record(world, rehearse, affinity):
+def scale_record(world, rehearse, affinity, dist=None):
     """What the N-rank figure is and is not (VERDICT r03 weak #5): said in the line itself, not only in README."""
     rec = {"world": world, "measured_on_hardware": bool(world > 1 and not rehearse), "rank_affinity": affinity,
+           "process_group": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
+                              "forced_one_rank": os.environ.get("NIG_BENCH_FORCE_PG") == "1" and world == 1}
+                             if grouped(dist) else None),
            "exchange": "all-gather of 13 float64 partial sums per rank after the timed region + fixed-order combine "
                        "(no data-path collective)"}
-    if world == 1:
+    if world == 1 and rec["process_group"]:
+        rec["note"] = ("single-GPU line through a ONE-RANK process group (NIG_BENCH_FORCE_PG=1): the barrier, the all-gathers of the rank "
+                       "times and of the tally partials and the object gather ran through the group's backend -- the code path of an N > 1 "
+                       "run, executed; no scaling information")
+    elif world == 1:
         rec["note"] = ("single-GPU line: no scaling information.  No 8-GPU node has been available to this build in any round: "
                        "the N > 1 path (rank launch, sharding by global lane index, RCCL tally exchange, nig_reduce_metrics) is "
                        "covered by 2-rank gloo tests on CPU and a 2-ranks-on-one-GPU rehearsal only; nig_reduce_metrics has only "
@@ -640,6 +806,7 @@ def parse_args(argv=None):
                     help="--env mixed: one kernel launch over all segments (nig_create_mixed) or one launch per segment on its own stream")
     ap.add_argument("--no-step-api", action="store_true", help="skip the secondary step-API measurement")
     ap.add_argument("--no-powergrid", action="store_true", help="skip the secondary PowerGrid (BASELINE configs[2]/[4]) measurement")
+    ap.add_argument("--no-robotassembly", action="store_true", help="skip the secondary RobotAssembly measurement (the third reference env, 262144 lanes)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the secondary mixed-batch (BASELINE configs[3]) measurement")
     ap.add_argument("--no-single-env", action="store_true", help="skip the BASELINE configs[0] record (1 env, 1000 steps, host loop)")
     ap.add_argument("--no-brackets", action="store_true",
@@ -686,17 +853,31 @@ def main():
         dev_index = 0 if rehearse else local_rank
         torch.cuda.set_device(dev_index)
         device = torch.device("cuda", dev_index)
-    if world > 1:
+    # NIG_BENCH_FORCE_PG=1: a process group even at world == 1 -- a one-rank "nccl" (RCCL) group is legal on one GPU and takes
+    # every collective branch below; it yields no scaling number (scale.measured_on_hardware stays false)
+    force_pg = os.environ.get("NIG_BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:          # (FORCE_PG without a launcher)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        if force_pg:
+            from neorl_industrial_gym_amd import parallel as _par
+            _par.ALWAYS_COLLECTIVE = True             # the tally all-gather goes through the backend even with one rank
     comm_dev = torch.device("cpu") if rehearse else device
+    if mode_r != "cpu":
+        global _PROBE, _DPM_DIR
+        _PROBE, _DPM_DIR = ClockProbe(ni, torch, device), gpu_sysfs_dir(torch, device.index or 0)
     affinity = [my_affinity]
-    if world > 1:
+    if grouped(dist):
         affinity = [None] * world
         dist.all_gather_object(affinity, my_affinity)
     if mode_r == "cpu":
@@ -754,9 +935,33 @@ def main():
                      "value": K3 * P * Bp * world / pw, "unit": "env-steps/s", "steps": K3, "ms_per_step": pw * 1e3 / K3,
                      "roofline": r3, "rank_times": pg_times,
                      "tally": {"episodes": int(ptotal[L.T_EPISODES]), "violations": int(ptotal[L.T_VIOL]),
-                               "critical": int(ptotal[L.T_CRIT])}, "tally_check": pcheck}
+                               "critical": int(ptotal[L.T_CRIT])}, "tally_check": pcheck,
+                     "fast_mode_statistics": fast_mode_statistics(ni, "pg", ptotal, Bp, 0 if args.no_parity else 1, device) if rank == 0 else None}
         w3.close()
         del w3
+
+    # ---- secondary: RobotAssembly-v0, 262144 lanes per GPU: the third reference env (robot_assembly.py:139-188, SURVEY rows
+    # a15-a19) has no BASELINE config of its own; timed at PowerGrid's batch so the line carries all three (VERDICT r04 next #6b)
+    robotassembly = None
+    if key == "cr" and args.mode == "rollout" and not args.no_robotassembly:
+        Br = BASELINE_BATCH["ra"]
+        # 40 ring slots = 294 MB: larger than the Infinity Cache, every action read is an HBM read (as for PowerGrid above)
+        w4 = Workload(ni, torch, "ra", Br, device, rank, "rollout", P, 40, args.outputs, args.traj)
+        K4 = max(2, min(K, 8))
+        ra_times = {}
+        rw, rd_ = timed(torch, dist, world, comm_dev, w4, K4, 2, args.settle, stats=ra_times)
+        r4 = roofline_of(w4, K4, rd_)
+        rtotal, rcheck = gathered_tally(torch, dist, world, comm_dev, w4)
+        L = ni._lib
+        robotassembly = {"workload": f"RobotAssembly-v0, batch={Br} per GPU x {world} GPU(s) = {Br * world} lanes, fused rollout, "
+                                     f"{P} env.step per launch, outputs: {args.outputs}",
+                         "value": K4 * P * Br * world / rw, "unit": "env-steps/s", "steps": K4, "ms_per_step": rw * 1e3 / K4,
+                         "roofline": r4, "rank_times": ra_times,
+                         "tally": {"episodes": int(rtotal[L.T_EPISODES]), "violations": int(rtotal[L.T_VIOL]),
+                                   "critical": int(rtotal[L.T_CRIT])}, "tally_check": rcheck,
+                         "fast_mode_statistics": fast_mode_statistics(ni, "ra", rtotal, Br, 0 if args.no_parity else 1, device) if rank == 0 else None}
+        w4.close()
+        del w4
 
     # ---- secondary: all 7 envs mixed-batch, 1 048 576 lanes per GPU (BASELINE configs[3]), ONE fused launch
     mixed = None
@@ -782,6 +987,9 @@ def main():
     wl.close()
     del wl
     parity = parity_probe_cpu(parity_gpu, key, B) if parity_gpu is not None else None
+    fast_stats = None
+    if rank == 0 and key in ENVS and args.mode == "rollout":     # untimed, after every timed region: a few launches with fresh actions
+        fast_stats = fast_mode_statistics(ni, key, total, B, 0 if args.no_parity else (2 if key == "cr" else 1), device)
 
     if rank == 0:
         L = ni._lib
@@ -803,7 +1011,7 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
             "roofline": roof,
             "rank_times": rank_times,
-            "scale": scale_record(world, rehearse, affinity),
+            "scale": scale_record(world, rehearse, affinity, dist),
             "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
                       "critical": int(total[L.T_CRIT]), "return_mean": float(total[L.T_RET_SUM] / max(total[L.T_EPISODES], 1))},
             "tally_check": tally_check,
@@ -814,14 +1022,16 @@ def main():
             out["step_api"] = step_api
         if powergrid is not None:
             out["powergrid"] = powergrid
+        if robotassembly is not None:
+            out["robotassembly"] = robotassembly
         if mixed is not None:
             out["mixed"] = mixed
-        if parity is not None:
-            out["parity"] = parity
+        if parity is not None or key in ENVS:
+            out["parity"] = dict(parity or {}, fast_mode_statistics=fast_stats)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(key, B, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if grouped(dist):
         dist.destroy_process_group()
 
 
@@ -839,10 +1049,10 @@ def rehearse_cpu(args, ni, torch, dist, comm_dev, world, rank, affinity):
                           "episodes_per_rank": check["episodes_per_rank"], "steps": K, "warmup": W,
                           "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "none", "rehearsal": "cpu control flow only: no device workload ran",
-                          "rank_times": rank_times, "scale": scale_record(world, True, affinity),
+                          "rank_times": rank_times, "scale": scale_record(world, True, affinity, dist),
                           "tally": {"episodes": int(total[L.T_EPISODES]), "violations": int(total[L.T_VIOL]),
                                     "critical": int(total[L.T_CRIT])}, "tally_check": check}))
-    if world > 1:
+    if grouped(dist):
         dist.destroy_process_group()
     return 0
 
@@ -965,7 +1175,7 @@ def bench_mixed(args, ni, torch, dist, device, comm_dev, world, rank):
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"],
             "per_env": rec["per_env"]}))
-    if world > 1:
+    if grouped(dist):
         dist.destroy_process_group()
     return 0
 

@@ -78,7 +78,13 @@ extern "C" {
 #define NIG_MAX_BATCH (1 << 24)         /* lanes per handle: row offsets stay 32-bit scalars */
 #define NIG_MAX_PITCH (1 << 26)         /* largest caller row pitch (elements)               */
 
-/* rows of the tally array (NIG_F_TALLY), all stored as double, one column per lane */
+/* rows of the tally array (NIG_F_TALLY), all stored as double, one column per lane.
+ * Count rows (EPISODES, LEN_SUM, VIOL, CRIT, SHUTDOWN, SUCCESS, SATISFIED, CONSTRAINTS) hold integers and every add to them is
+ * an integer-valued float64 add: EXACT while a sum stays below 2^53 = 9.0e15 -- per lane, per GPU after nig_reduce_tally, and
+ * across ranks after the rank-order combine ("counts must be reduced as integers, never fp32": no float32 is ever
+ * involved; at the headline's 6.7e9 violations per 0.6 s a single GPU would need ~9 days of continuous stepping to reach the
+ * bound).  A host that needs more sums the partial vectors of shorter runs (fresh handles) in integers itself;
+ * parallel.metrics_from_partial rounds the float64 sums to int, which is the identity below 2^53. */
 enum {
     NIG_T_EPISODES = 0,   /* finished episodes                                   utils.py:120 */
     NIG_T_RET_SUM,        /* sum of episode returns                              utils.py:130 */
@@ -164,6 +170,14 @@ int nig_tune(int32_t key, int64_t value);
 int64_t nig_tune_get(int32_t key);
 /* the value in effect for THIS handle (its own device's default unless an explicit setting exists); -1: NULL handle / unknown key */
 int64_t nig_handle_tune_get(const nig_handle *h, int32_t key);
+
+/* Measurement aid (no counterpart upstream: performance_benchmark.py:106-133 times its loop with time.time()).  Enqueues a
+ * 64-block kernel on `stream` of the CURRENT device that stamps, per XCD x (HW_REG_XCC_ID, 0-7), the shader-clock counter and
+ * the constant 100 MHz counter into the caller's DEVICE buffer: out[2 x] = s_memtime, out[2 x + 1] = s_memrealtime (16 uint64;
+ * an XCD no block landed on keeps its old words).  Two stamps around a run of launches give the clock the chip held over
+ * that run: (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz, per XCD -- bench.py records it next to every timed
+ * region so that box-to-box spread of a line can be attributed.  Never part of a timed kernel. */
+int nig_clock_stamp(void *stream, uint64_t *out16);
 
 /* utils.make registry lookup (utils.py:26-35): name -> id, or -1 */
 int nig_env_id(const char *name);

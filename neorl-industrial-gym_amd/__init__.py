@@ -20,13 +20,14 @@ from .envs import (AdvancedChemicalReactorEnv, AdvancedPowerGridEnv, ChemicalRea
                    IndustrialEnv, PowerGridEnv, RobotAssemblyEnv, SteelAnnealingEnv, SupplyChainEnv, WaterTreatmentEnv)
 from .policies import (DevicePolicy, MLPPolicy, behaviour_policy, constant_agent, mpc_agent,  # noqa: E402
                        pid_agent, random_agent)
-from .utils import evaluate_with_safety, make, make_batched  # noqa: E402
+from .utils import evaluate_with_safety, make, make_batched, uniform_action_statistics  # noqa: E402
 
 def tune(split_blocks=None, wide_min_blocks=None):
     """Process-wide kernel-selection knobs of libnig (include/nig.h nig_tune); results never depend on them.
     split_blocks: largest batch, in 256-lane blocks, that rollout() runs in the three-wave form (0 = never).
     wide_min_blocks: smallest batch, in 512-lane blocks, that rollout() runs in the wide form (PowerGrid).
-    -1 removes an explicit setting (back to the per-device default: the device's compute-unit count).
+    -1 removes an explicit setting (back to the per-device defaults: split_blocks = the device's compute-unit count,
+    wide_min_blocks = 1.5 x the compute units + 1 -- the first batch that no longer fits one round of the 256-lane form).
     Returns the current settings."""
     L = _lib.lib()
     if split_blocks is not None:
@@ -43,6 +44,6 @@ __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",
     "ChemicalReactorEnv", "PowerGridEnv", "RobotAssemblyEnv", "AdvancedChemicalReactorEnv", "AdvancedPowerGridEnv",
     "HVACControlEnv", "WaterTreatmentEnv", "SteelAnnealingEnv", "SupplyChainEnv", "BatchedIndustrialEnv", "MixedBatchedEnv", "StepInfo",
-    "make", "make_batched", "evaluate_with_safety", "tune", "DevicePolicy", "MLPPolicy", "behaviour_policy", "constant_agent",
+    "make", "make_batched", "evaluate_with_safety", "uniform_action_statistics", "tune", "DevicePolicy", "MLPPolicy", "behaviour_policy", "constant_agent",
     "mpc_agent", "pid_agent", "random_agent",
 ]

@@ -37,7 +37,7 @@ SYMBOLS = [
     "nig_step64", "nig_step_host64", "nig_reduce_metrics",
     "nig_create_mixed", "nig_mixed_destroy", "nig_mixed_get_info", "nig_mixed_state", "nig_mixed_segment", "nig_mixed_reset",
     "nig_mixed_fill_actions", "nig_mixed_rollout", "nig_rollout_mixed", "nig_mixed_step", "nig_rollout_mixed_obs", "nig_mixed_rollout_obs",
-    "nig_tune", "nig_tune_get", "nig_handle_tune_get",
+    "nig_tune", "nig_tune_get", "nig_handle_tune_get", "nig_clock_stamp",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
     L.nig_tune_get.restype = C.c_int64
     L.nig_handle_tune_get.argtypes = [C.c_void_p, C.c_int32]
     L.nig_handle_tune_get.restype = C.c_int64
+    L.nig_clock_stamp.argtypes = [C.c_void_p, C.c_void_p]
     L.nig_env_id.argtypes = [C.c_char_p]
     L.nig_env_name.restype = C.c_char_p
     L.nig_env_name.argtypes = [C.c_int]

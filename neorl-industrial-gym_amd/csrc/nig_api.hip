@@ -26,6 +26,15 @@ __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
 
+// nig_clock_stamp: one wave per block, enough blocks that the dispatcher's round robin reaches every XCD; blocks of one XCD
+// write the same pair of words with values a few hundred cycles apart (any of them will do)
+__global__ void __launch_bounds__(64) clock_stamp_kernel(unsigned long long *o)
+{
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;      // HW_REG_XCC_ID (id 20), bits 3:0
+    if (threadIdx.x == 0) { o[2 * xcc] = t; o[2 * xcc + 1] = r; }
+}
+
 // n_total = the handle's enabled built-in constraints (3, 4 for AdvancedChemicalReactor, fewer after
 // nig_set_constraint_mask): SafetyMetrics.total_constraints, base.py:115
 __global__ void __launch_bounds__(BLOCK) safety_metrics_kernel(const uint32_t *flags, int32_t *out, int64_t ld_out,
@@ -256,8 +265,12 @@ static int ring_check(nig_handle *h, hipStream_t st, const char *who)
     HIP_TRY(hipMemcpy(&code, h->t_dev + 16, 4, hipMemcpyDeviceToHost));
     if (code != 0u) {
         HIP_TRY(hipMemset(h->t_dev + 16, 0, 4));
-        static const char *const ring[3] = {"inputs (producer -> stepper)", "results (stepper -> recorder)", "slots released (consumer -> producer)"};
-        char detail[256];
+        // the counter index means different rings per kernel family: three-wave kernels (nig_split*.hpp) have
+        // {produced inputs, stepped results, released slots}; PowerGrid's paired kernels (nig_pg_lds.hpp) {produced draws, consumed}
+        static const char *const ring3[3] = {"inputs (producer -> stepper)", "results (stepper -> recorder)", "slots released (consumer -> producer)"};
+        static const char *const ring2[3] = {"draws (producer -> stepper)", "slots released (stepper -> producer)", "(no such counter in the paired form)"};
+        const char *const *ring = (h->env == NIG_ENV_POWER_GRID) ? ring2 : ring3;
+        char detail[320];
         snprintf(detail, sizeof detail, "%s: a wave waited more than %d polls for count %u of ring counter %u, '%s'; every role left its loop, "
                  "results of this launch are invalid", who, (int)(NIG_RING_SPIN_LIMIT), (code >> 16) & 0x7FFFu, code & 3u, ring[(code & 3u) % 3]);
         return fail(NIG_ERR_HIP, "ring protocol time-out -- %s", detail);
@@ -349,6 +362,14 @@ int64_t nig_handle_tune_get(const nig_handle *h, int32_t key)
     return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::split_blocks_for(h->cus) : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::wide_min_blocks_for(h->cus) : -1;
 }
 
+int nig_clock_stamp(void *stream, uint64_t *out16)
+{
+    if (!out16) return fail(NIG_ERR_INVALID, "nig_clock_stamp: NULL buffer%s");
+    hipLaunchKernelGGL(nig::clock_stamp_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out16);
+    HIP_TRY(hipGetLastError());
+    return NIG_OK;
+}
+
 int nig_env_id(const char *name)
 {
     if (!name) return -1;
@@ -433,8 +454,13 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof at);
         const hipError_t pe = hipPointerGetAttributes(&at, workspace);
-        if (pe != hipSuccess) { (void)hipGetLastError(); delete h; return fail(NIG_ERR_INVALID, "nig_create: workspace is not a device allocation (%s)", hipGetErrorString(pe)); }
-        if (at.type != hipMemoryTypeDevice || at.device != device) {
+        // Rejected: memory POSITIVELY identified as host, managed or another device's.  A query that fails (device-local
+        // memory mapped through the virtual-memory API -- hipMemCreate / hipMemMap, e.g. torch's expandable_segments allocator --
+        // is not known to hipPointerGetAttributes on every ROCm release) or that reports a type this code does not know is
+        // accepted: the caller has stated in the contract that it is device-local memory of `device`.
+        if (pe != hipSuccess) (void)hipGetLastError();
+        else if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged || at.isManaged ||
+                 (at.type == hipMemoryTypeDevice && at.device != device)) {
             delete h;
             return fail(NIG_ERR_INVALID, "nig_create: workspace must be ordinary device-local memory of `device` (hipMalloc / a torch CUDA tensor), "
                                          "not host-pinned, managed or another device's memory%s");

@@ -313,6 +313,8 @@ __device__ const float4 NIG_PROBIT[768] = {
 #include "nig_probit_table.inc"
 };
 
+constexpr int PROBIT_BIAS = 192;      // see probit_fetch: an LDS copy of the table belongs at byte 16 x PROBIT_BIAS or above
+
 // In two halves so a kernel can put other work between the LDS read and its use.
 struct ProbitFetch { float4 c; float t; uint32_t word; };
 
@@ -320,12 +322,34 @@ __device__ __forceinline__ ProbitFetch probit_fetch(uint32_t word, const float4 
 {
     ProbitFetch f;
     f.word = word;
-    // 4 (m + 1/2) = 4 m + 2, exact (one bit-field extract, one fused multiply-add): the same mantissa as m + 1/2 with the exponent
-    // field two higher -- 128 .. 151 for the 24 binades, so the piece number (binade x 32 + top five mantissa bits) is bits
-    // 27 .. 18 as they stand, no subtraction of the first binade's exponent: one instruction less per normal, same bits
+    // 64 (4 m + 2) = 256 m + 128 = the word with its sign bit and low byte replaced by 0x80: ONE v_and_or_b32 on the word as it
+    // stands, then the conversion -- exact, since 2 m + 1 is an odd 24-bit integer (tests/test_host_logic.py checks all 2^23 m).
+    // Same mantissa as m + 1/2, exponent field 134 .. 157 for the 24 binades: the piece number (binade x 32 + top five mantissa
+    // bits) is bits 27 .. 18 as they stand, plus PROBIT_BIAS = (134 & 31) x 32 = 192 -- a constant that rides in the address
+    // (the DS instruction's offset field when the table sits at LDS byte PROBIT_BIAS x 16 = 3 072 or above; the global load's
+    // immediate otherwise).  Round 4 extracted m (v_bfe_u32), converted it and formed 4 m + 2 by a fused multiply-add: one
+    // instruction more per normal for the same bits.
+    // (the mask lives in a VECTOR register: v_and_or_b32 may carry one literal, and 0x80 is not an inline constant -- with both
+    // as literals hipcc emits v_and_b32 + v_or_b32, i.e. nothing saved; the asm has no inputs, identical copies are merged and
+    // hoisted: one v_mov_b32 per kernel, like opaque_zero64)
+#ifdef NIG_DIAG_PROBIT_R04             // (diagnostic builds only: round 4's three-instruction form, for same-box A/Bs)
     const float x = __builtin_fmaf((float)__builtin_amdgcn_ubfe(word, 8, 23), 4.0f, 2.0f);
     const uint32_t b = f32_bits(x);
-    f.c = tab[(b >> 18) & 0x3FFu];
+    tab += PROBIT_BIAS;                    // (its piece numbers start at 0)
+#else
+    uint32_t keep;
+    asm("v_mov_b32 %0, 0x7fffff00" : "=v"(keep));
+    const float x = (float)((word & keep) | 0x80u);
+    const uint32_t b = f32_bits(x);
+#endif
+#ifdef NIG_DIAG_PROBIT_NOCONFLICT      // (diagnostic builds only, profiles/r05: what would a conflict-free gather be worth?  Lane l reads the
+    // entry of ITS 16-byte slot in the wanted entry's 256-byte bank row -- a neighbouring piece, so the values are off by less than
+    // half a binade and the workload's statistics barely move, but no two lanes of a ds_read_b128 group share a bank: same
+    // instruction count (v_and_or_b32 for v_and_b32), zero bank conflicts)
+    f.c = (tab - PROBIT_BIAS)[((b >> 18) & 0x3F0u) | (__builtin_amdgcn_workitem_id_x() & 15u)];
+#else
+    f.c = (tab - PROBIT_BIAS)[(b >> 18) & 0x3FFu];
+#endif
     f.t = (float)(b & 0x3FFFFu);       // position in the piece as an integer: its 2^-18 is folded into the table's coefficients (bit-identical, tests/probit_scale_check.c)
     return f;
 }

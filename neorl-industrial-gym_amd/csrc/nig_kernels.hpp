@@ -659,7 +659,7 @@ template <class Env, int OUT, int BLK = 256>
 struct RolloutLds {
     static constexpr int BLOCK = BLK;            // shadows the file-wide constant
     static constexpr int NWAVE = BLOCK / 64;
-    static constexpr int OFF_PROBIT = 0;
+    static constexpr int OFF_PROBIT = 16 * PROBIT_BIAS;     // (nig_detmath.hpp probit_fetch: the piece number's bias rides in the DS offset field)
     // Per-wave scratch: the cooperative reset's image [RESET_ROWS][64] and, for the row-major trajectory, the transpose
     // image [16 S] float4 -- ONE region for both (a wave uses them at different points of its step, and its DS
     // operations execute in order).  Separate regions put RobotAssembly's row-major kernel at 66 KB per block, two

@@ -31,10 +31,13 @@ namespace nig {
 template <int BLK>
 struct PgLds {
     static constexpr int NWAVE = BLK / 64;
-    static constexpr int OFF_PROBIT = 0;
-    static constexpr int OFF_IMG = 768 * 16;                     // float4 [NWAVE][512]
-    static constexpr int OFF_WLIST = OFF_IMG + NWAVE * 8192;     // uchar [NWAVE][64]
-    static constexpr int BYTES = OFF_WLIST + NWAVE * 64;
+    // the generator's table at LDS byte 16 x PROBIT_BIAS (3 072), so that probit_fetch's piece number needs no subtraction: the
+    // bias rides in the DS instruction's offset field (nig_detmath.hpp); the reset's work lists live in the bytes below it
+    static constexpr int OFF_WLIST = 0;                          // uchar [NWAVE][64]
+    static constexpr int OFF_PROBIT = 16 * PROBIT_BIAS;
+    static_assert(NWAVE * 64 <= OFF_PROBIT, "work lists below the table");
+    static constexpr int OFF_IMG = OFF_PROBIT + 768 * 16;        // float4 [NWAVE][512]
+    static constexpr int BYTES = OFF_IMG + NWAVE * 8192;
 };
 
 // The PAIRED form (rollout_pg_pair_kernel below; batches of at most one 256-lane block per compute unit, where the body
@@ -334,10 +337,17 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
             ngen7 = ngen[7];
             // refill this action register set (step it + DEPTH), issued before the step's stores: see rollout_body
             if constexpr (!POLICY) {
+#ifdef NIG_DIAG_PG_NOACTLOAD           // (diagnostic builds only, profiles/r05: no global load in the loop, hence no vmcnt wait that the
+            // step's stores could hold up -- the action is a cheap hash of lane and step instead; what is the in-order wait worth?)
+#pragma unroll
+            for (int k = 0; k < A; ++k)
+                abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+#else
 #pragma unroll
             for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
             slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
             act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------

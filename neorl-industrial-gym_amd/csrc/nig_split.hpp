@@ -46,8 +46,8 @@ struct SplitLds {
     static constexpr int HI_ROWS = Env::KS + Env::A;
     static constexpr int HI_SLOT = HI_ROWS * 64;             // floats
     static constexpr int IH_SLOT = (Env::S + 1) * 64;        // floats: [64][S] state rows, then [64] violation words
-    static constexpr int OFF_PROBIT = 0;
-    static constexpr int OFF_IMG = 768 * 16;                                   // float [NP][RESET_ROWS][64]
+    static constexpr int OFF_PROBIT = 16 * PROBIT_BIAS;                        // (probit_fetch: the bias rides in the DS offset field)
+    static constexpr int OFF_IMG = OFF_PROBIT + 768 * 16;                                   // float [NP][RESET_ROWS][64]
     static constexpr int OFF_WLIST = OFF_IMG + NP * Env::RESET_ROWS * 64 * 4;  // uchar [NP][64]
     static constexpr int OFF_SYNC = OFF_WLIST + NP * 64;                       // uint32 [NP][4]: {P produced, I produced, C done}
     static constexpr int OFF_HI = OFF_SYNC + NP * 16;

@@ -27,8 +27,8 @@ struct SplitPolicyLds {
     static constexpr int HI_SLOT = HI_ROWS * 64;                       // floats
     static constexpr int OBS_ROWS = BIG ? 0 : Env::S;                  // [64][S] observation acted on (for the transition stream)
     static constexpr int IH_SLOT = (OBS_ROWS + Env::S + 1 + Env::A) * 64;   // observation, [64][S] post-dynamics state, violation words, [A][64] action
-    static constexpr int OFF_PROBIT = 0;
-    static constexpr int OFF_POL = 768 * 16;
+    static constexpr int OFF_PROBIT = 16 * PROBIT_BIAS;
+    static constexpr int OFF_POL = OFF_PROBIT + 768 * 16;
     static constexpr int OFF_WD = OFF_POL + (int)((sizeof(nig_policy) + 15) / 16 * 16);      // BIG: dense [S rounded up to 8][8] feedback matrix
     static constexpr int OFF_IMG = OFF_WD + (BIG ? (Env::S + 7) / 8 * 8 * 8 * 4 : 0);
     static constexpr int OFF_WLIST = OFF_IMG + NP * Env::RESET_ROWS * 64 * 4;

@@ -16,6 +16,11 @@ import torch
 from . import _lib
 
 
+# True: all_gather_partials calls the backend's all-gather even in a one-rank group (bench.py NIG_BENCH_FORCE_PG=1 and
+# tests/test_gpu_rccl_one_rank.py: the RCCL call path executed on a one-GPU box).  Default: a one-rank job has nothing to gather.
+ALWAYS_COLLECTIVE = False
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split of `total` lanes: (first global lane, lane count) of `rank`."""
     if not (0 <= rank < world):
@@ -41,7 +46,7 @@ def all_gather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
     """Every rank's partial vector, [world, T_ROWS], in rank order (identical on every rank)."""
     import torch.distributed as dist
     flat = partial.contiguous().reshape(-1)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not ALWAYS_COLLECTIVE):
         return flat.reshape(1, -1)
     world = dist.get_world_size(group)
     gathered = [torch.empty_like(flat) for _ in range(world)]

@@ -166,3 +166,61 @@ def _evaluate_batched(agent, env: BatchedIndustrialEnv, n_episodes: int, step_no
     if reduce_across_ranks and dist.is_available() and dist.is_initialized():
         n_total = int(round(float(total[_lib.T_EPISODES].item())))
     return metrics_from_partial(total, n_total)
+
+
+def uniform_action_statistics(env_id: str, batch: int, episodes_per_lane: int, device="cuda:0", seed: int = 0xBEEF,
+                              plan_steps: int = 250, outputs: str = "min") -> Dict[str, Any]:
+    """Episode statistics of the reference's measurement loop (performance_benchmark.py:106-133: a uniform random action per
+    step, reset on done) in FAST MODE -- fused rollout launches, in-kernel generator, auto-reset -- over the first
+    `episodes_per_lane` episodes of every lane.  A fixed episode count per lane is an unbiased sample ("episodes finished
+    inside a window of steps" favours short ones); every step gets a fresh action (slot k of a `plan_steps`-slot ring, refilled
+    for every launch).  All reductions run on the device from the per-step flag words and rewards the kernel writes.
+    Returns sums over the counted episodes: episodes, steps, viol (base.py:179-183 violation counts), crit, c0..c2 (steps on
+    which built-in constraint k failed), term / trunc / shut (how the episodes ended), ret (sum of rewards), hist (episode
+    lengths, index = length), launches.  outputs: "min" = reward + flag rows; "full" also writes the observation
+    trajectory (the kernel instantiation bench.py's headline times)."""
+    L = _lib
+    env = make_batched(env_id, batch, device=device, seed=seed, autoreset=True)
+    dev, B, K, P = env.device, env.batch, int(episodes_per_lane), int(plan_steps)
+    env.reset()
+    ring = torch.empty(P, env.action_dim, env.ld, dtype=torch.float32, device=dev)
+    rew = torch.empty(P, env.ld, dtype=torch.float32, device=dev)
+    fl = torch.empty(P, env.ld, dtype=torch.int32, device=dev)
+    traj = torch.empty(P, B, env.state_dim, dtype=torch.float32, device=dev) if outputs == "full" else None
+    epcount = torch.zeros(B, dtype=torch.int32, device=dev)
+    acc = {k: torch.zeros((), dtype=torch.int64, device=dev)
+           for k in ("steps", "viol", "crit", "c0", "c1", "c2", "episodes", "term", "trunc", "shut")}
+    ret = torch.zeros((), dtype=torch.float64, device=dev)
+    hist = torch.zeros(env.max_episode_steps + 1, dtype=torch.int64, device=dev)
+    launches = t = 0
+    while True:
+        for s in range(P):
+            t += 1
+            env.fill_actions(7000 + t, ring[s])
+        env.rollout(P, ring, rew, fl, traj)
+        f = fl[:, :B]
+        done = (f & (L.FLAG_TERMINATED | L.FLAG_TRUNCATED)) != 0
+        cum = done.cumsum(0, dtype=torch.int32)
+        valid = (epcount.unsqueeze(0) + cum - done.to(torch.int32)) < K          # the step belongs to one of the lane's first K episodes
+        acc["steps"] += valid.sum()
+        acc["viol"] += ((((f >> L.FLAG_NVIOL_SHIFT) & 3) + ((f >> 13) & 1) * 4) * valid).sum()
+        acc["crit"] += (((f >> L.FLAG_NCRIT_SHIFT) & 3) * valid).sum()
+        for k in range(3):
+            acc[f"c{k}"] += (((f >> (L.FLAG_VIOL_SHIFT + k)) & 1) * valid).sum()
+        ret += (rew[:, :B].to(torch.float64) * valid).sum()
+        dv = done & valid
+        acc["episodes"] += dv.sum()
+        acc["term"] += (dv & ((f & L.FLAG_TERMINATED) != 0)).sum()
+        acc["trunc"] += (dv & ((f & L.FLAG_TRUNCATED) != 0)).sum()
+        acc["shut"] += (dv & ((f & L.FLAG_SHUTDOWN) != 0)).sum()
+        hist += torch.bincount(((f >> L.FLAG_STEP_SHIFT) & 0xFFFF)[dv].to(torch.int64), minlength=hist.numel())[:hist.numel()]
+        epcount += cum[-1]
+        launches += 1
+        if int(epcount.min().item()) >= K:
+            break
+        if launches * P > K * env.max_episode_steps + P:
+            raise RuntimeError("a lane did not finish its episodes within episodes_per_lane x max_episode_steps steps")
+    out: Dict[str, Any] = {k: int(v.item()) for k, v in acc.items()}
+    out.update(ret=float(ret.item()), hist=hist.cpu().numpy(), launches=launches, batch=B, episodes_per_lane=K)
+    env.close()
+    return out

@@ -9,7 +9,7 @@ cfgs=("$@")
 for r in 1 2; do for v in $variants; do
   if [ "$v" = base ]; then unset NIG_LIB_PATH; else export NIG_LIB_PATH=$PWD/neorl-industrial-gym_amd/libnig_$v.so; fi
   for cfg in "${cfgs[@]}"; do read -r e b o t extra <<< "$cfg"; echo -n "$v $cfg: "
-    timeout -k 10 100 python bench.py --env $e --batch $b --outputs $o --traj $t $extra --steps 40 --warmup 8 --settle 0.4 --no-cpu-baseline --no-step-api --no-parity --no-powergrid --no-mixed --no-brackets 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('%.3e  launch_us %.1f  frac %.3f' % (d['value'], d['roofline']['launch_us'], d['roofline']['frac']))"
+    timeout -k 10 100 python bench.py --env $e --batch $b --outputs $o --traj $t $extra --steps 40 --warmup 8 --settle 0.4 --no-cpu-baseline --no-step-api --no-parity --no-powergrid --no-mixed --no-robotassembly --no-brackets 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('%.3e  launch_us %.1f  frac %.3f' % (d['value'], d['roofline']['launch_us'], d['roofline']['frac']))"
   done
 done; done
 unset NIG_LIB_PATH

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
 export NIG_NO_AUTOBUILD=1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $out/$ctr -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api --no-mixed --no-brackets --no-single-env --settle 0 --calibrate "$@" > $out/bench_$ctr.json 2> $out/bench_$ctr.err || { tail -20 $out/bench_$ctr.err; exit 1; }
+  rocprofv3 --pmc $ctr --output-format csv -d $out/$ctr -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api --no-mixed --no-robotassembly --no-brackets --no-single-env --settle 0 --calibrate "$@" > $out/bench_$ctr.json 2> $out/bench_$ctr.err || { tail -20 $out/bench_$ctr.err; exit 1; }
   f=$(find $out/$ctr -name "*counter_collection.csv" | head -1)
   cp $f $out/${tag}_${ctr}.csv
 done

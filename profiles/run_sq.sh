@@ -10,7 +10,7 @@ python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
 export NIG_NO_AUTOBUILD=1
 # NIG_SQ_COUNTERS overrides the counter set of the pass (e.g. the LDS set: SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD)
 ctrs=${NIG_SQ_COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY}
-rocprofv3 --pmc $ctrs --output-format csv -d $out -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api --no-mixed --no-brackets --no-single-env --settle 0 "$@" > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
+rocprofv3 --pmc $ctrs --output-format csv -d $out -o $tag -- python3 bench.py --no-cpu-baseline --no-parity --no-step-api --no-mixed --no-robotassembly --no-brackets --no-single-env --settle 0 "$@" > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

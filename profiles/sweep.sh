@@ -4,7 +4,7 @@
 tag=$1; out=gpurun_out/sweep_$tag.jsonl; mkdir -p gpurun_out; : > $out
 python3 -c 'import __graft_entry__ as g; g.build(force=False)' > /dev/null
 export NIG_NO_AUTOBUILD=1
-run() { echo "# $*" >> $out; timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity --no-powergrid --no-mixed --no-brackets --no-single-env "$@" 2>/dev/null >> $out; }
+run() { echo "# $*" >> $out; timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity --no-powergrid --no-mixed --no-robotassembly --no-brackets --no-single-env "$@" 2>/dev/null >> $out; }
 run --env cr --batch 65536 --outputs full --steps 60 --warmup 10
 run --env cr --batch 65536 --outputs min --no-step-api --steps 60 --warmup 10
 run --env cr --batch 65536 --outputs none --no-step-api --steps 60 --warmup 10

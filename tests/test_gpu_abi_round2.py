@@ -281,3 +281,49 @@ def test_reduce_metrics_through_rccl(ni):
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
     mix.close()
+
+
+def test_workspace_kinds_nig_create_accepts_and_rejects(ni):
+    """nig_create's caller workspace (include/nig.h): memory positively identified as host-pinned is refused (the step
+    kernel's float64 hardware atomics execute at the memory side and would miscount there); a torch CUDA tensor is taken;
+    a failing or unknown attribute query is NOT a refusal (device memory mapped through the virtual-memory API)."""
+    L = ni._lib.lib()
+    lay = ni._lib.layout_query(0, 1024, ni._lib.F_AUTORESET | ni._lib.F_TALLY)
+    pinned = torch.empty(int(lay.bytes) + 256, dtype=torch.uint8).pin_memory()
+    p = (pinned.data_ptr() + 255) // 256 * 256
+    h = C.c_void_p()
+    rc = L.nig_create(0, 1024, 0, C.c_uint64(1), C.c_uint64(0), 0, C.c_double(0.0), ni._lib.F_AUTORESET | ni._lib.F_TALLY, C.c_void_p(p), C.byref(h))
+    assert rc != 0 and b"device-local" in L.nig_last_error()
+    dev = torch.empty(int(lay.bytes), dtype=torch.uint8, device="cuda")
+    rc = L.nig_create(0, 1024, 0, C.c_uint64(1), C.c_uint64(0), 0, C.c_double(0.0), ni._lib.F_AUTORESET | ni._lib.F_TALLY,
+                      C.c_void_p(dev.data_ptr()), C.byref(h))
+    assert rc == 0, L.nig_last_error()
+    assert L.nig_destroy(h) == 0
+
+
+EXPANDABLE_CHILD = r'''
+import torch
+import neorl_industrial_gym_amd as ni
+env = ni.make_batched("ChemicalReactor-v0", 4096, autoreset=True, tally=True)      # workspace = a tensor of the expandable-segments allocator
+env.reset()
+ring = torch.empty(4, 3, env.ld, device="cuda")
+for s in range(4):
+    env.fill_actions(10 + s, ring[s])
+env.rollout(600, ring)
+part = env.reduce_tally()
+assert int(part[ni._lib.T_EPISODES]) > 0
+print("ok", torch.cuda.memory_stats().get("segment.all.current", -1))
+'''
+
+
+def test_workspace_from_the_expandable_segments_allocator_is_accepted():
+    """The same handle on a workspace that torch mapped through hipMemCreate / hipMemMap (PYTORCH_CUDA_ALLOC_CONF=
+    expandable_segments:True; a release that does not support the option ignores it with a warning): accepted and usable."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTORCH_CUDA_ALLOC_CONF="expandable_segments:True", PYTORCH_HIP_ALLOC_CONF="expandable_segments:True",
+               NIG_NO_AUTOBUILD="1")
+    p = subprocess.run([sys.executable, "-c", EXPANDABLE_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-1000:], p.stderr[-3000:])

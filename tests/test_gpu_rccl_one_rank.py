@@ -1,0 +1,105 @@
+"""-m gpu: the torch.distributed "nccl" (= RCCL on ROCm) code path of bench.py and parallel.py EXECUTED on the one GPU a
+build box has.  Until round 5 every N > 1 rehearsal used gloo and a world of one skipped
+init_process_group altogether, so the first 8-GPU run would also have been RCCL's first contact with this code.
+
+A ONE-rank "nccl" group is legal on one GPU.  NIG_BENCH_FORCE_PG=1 makes bench.py build it and take every branch an
+N > 1 run takes: init_process_group("nccl", device_id=...), the NCCL barriers around the timed region, the all_gather of
+the per-rank times (device tensors), all_gather_object of the affinity records, the all-gather of the tally partials
+(parallel.ALWAYS_COLLECTIVE), destroy_process_group.  No scaling number comes out of this and the line says so
+(scale.measured_on_hardware false).  The reference has no collective to compare with
+(optimization/distributed_training.py:164-181 is single-process; SURVEY finding 3): this is SURVEY 8(e) readiness, not parity.
+
+Each case runs in a child interpreter started with plain subprocess (a process group per process; the child is started
+by torch.distributed.run exactly as the driver starts the N > 1 ranks)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BENCH_ARGS = ["--gpus", "1", "--steps", "40", "--warmup", "8", "--no-step-api", "--no-cpu-baseline", "--no-parity",
+              "--no-mixed", "--no-robotassembly", "--no-brackets", "--no-single-env"]
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _clean_env(**extra):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NIG_BENCH_REHEARSE", "NIG_BENCH_FORCE_PG"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["NIG_NO_AUTOBUILD"] = "1"
+    env.update(extra)
+    return env
+
+
+def _line(p):
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1])
+
+
+def test_bench_through_a_one_rank_rccl_group_matches_the_plain_run():
+    plain = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_ARGS, env=_clean_env(), cwd=ROOT,
+                                 capture_output=True, text=True, timeout=900))
+    forced = _line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                                   os.path.join(ROOT, "bench.py")] + BENCH_ARGS,
+                                  env=_clean_env(NIG_BENCH_FORCE_PG="1"), cwd=ROOT, capture_output=True, text=True, timeout=900))
+    assert plain["scale"]["process_group"] is None
+    pg = forced["scale"]["process_group"]
+    assert pg == {"backend": "nccl", "world": 1, "forced_one_rank": True}, pg
+    assert forced["scale"]["measured_on_hardware"] is False and "ONE-RANK" in forced["scale"]["note"]      # never a scaling figure
+    assert forced["n_gpus"] == 1 and forced["ranks"] == 1 and forced["tally_check"] == {**forced["tally_check"], "ranks": 1, "ok": True}
+    assert forced["rank_times"]["ranks"] == 1 and len(forced["rank_times"]["wall_s_per_rank"]) == 1
+    # the same workload from the same generator keys: the tallies of both runs are over the same launches only if settle ran
+    # equally long, so compare what is launch-count independent -- the rate, and the PowerGrid record's presence and self-check
+    assert forced["powergrid"]["tally_check"]["ok"] and forced["powergrid"]["tally_check"]["ranks"] == 1
+    assert forced["value"] == pytest.approx(plain["value"], rel=0.05), (forced["value"], plain["value"])
+    assert forced["powergrid"]["value"] == pytest.approx(plain["powergrid"]["value"], rel=0.05)
+
+
+CHILD = r'''
+import os, torch, torch.distributed as dist
+import neorl_industrial_gym_amd as ni
+from neorl_industrial_gym_amd import parallel
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+env = ni.make_batched("PowerGrid-v0", 4096, device=dev, seed=5, autoreset=True, tally=True)
+env.reset()
+ring = torch.empty(8, env.action_dim, env.ld, device=dev)
+for s in range(8):
+    env.fill_actions(100 + s, ring[s])
+env.rollout(64, ring)
+part = env.reduce_tally()                                   # device tensor, 13 float64 sums
+assert part.is_cuda and part.dtype == torch.float64
+local = parallel.combine_partials(part.reshape(1, -1))
+assert parallel.all_gather_partials(part).shape == (1, part.numel())          # default: a one-rank job gathers nothing
+parallel.ALWAYS_COLLECTIVE = True
+gathered = parallel.all_gather_partials(part)               # ncclAllGather on the device tensor
+assert gathered.is_cuda and gathered.shape == (1, part.numel())
+total = parallel.all_reduce_partial(part)
+assert torch.equal(total, local), (total, local)            # same bits: one rank, fixed-order combine
+dist.barrier()
+m = parallel.metrics_from_partial(total)
+assert m["safety_violations"] > 0 and int(total[ni._lib.T_EPISODES]) > 0
+dist.destroy_process_group()
+print("ok episodes", int(total[ni._lib.T_EPISODES]), "violations", m["safety_violations"])
+'''
+
+
+def test_all_reduce_partial_on_a_device_tensor_through_rccl():
+    env = _clean_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok episodes" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

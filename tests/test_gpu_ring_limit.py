@@ -67,6 +67,13 @@ for name, B, kind in cases:
     except ni._lib.NigError as e:
         msg = str(e)
         assert "ring protocol time-out" in msg and "polls" in msg, msg
+        # the ring is named per kernel family (ADVICE r04): PowerGrid's paired form has {draws, slots released}, the three-wave
+        # kernels {inputs, results, slots released}
+        if name == "PowerGrid-v0":
+            assert "'draws (producer -> stepper)'" in msg or "'slots released (stepper -> producer)'" in msg, msg
+        else:
+            assert "draws" not in msg and any(r in msg for r in ("'inputs (producer -> stepper)'", "'results (stepper -> recorder)'",
+                                                                 "'slots released (consumer -> producer)'")), msg
         print("reported:", name, kind, "--", msg[:160])
     assert L.nig_tune(ni._lib.TUNE_DIAG_RING_FAULT, 0) == 0
     env.reset()

@@ -33,7 +33,7 @@ def test_bench_two_ranks_on_one_gpu():
     env["NIG_BENCH_REHEARSE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8192", "--steps", "2",
                         "--warmup", "1", "--plan-steps", "250", "--settle", "0", "--no-step-api", "--no-cpu-baseline",
-                        "--no-parity", "--no-mixed", "--no-brackets"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-parity", "--no-mixed", "--no-robotassembly", "--no-brackets"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and len(rec["episodes_per_rank"]) == 2
