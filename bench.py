@@ -155,26 +155,27 @@ class ClockProbe:
 
     def __init__(self, ni, torch, device):
         self.L, self.torch = ni._lib.lib(), torch
-        self.buf = torch.zeros(2, 16, dtype=torch.int64, device=device)
+        self.buf = torch.zeros(2, 4096, dtype=torch.int64, device=device)        # NIG_CLOCK_STAMP_WORDS per stamp
 
     def stamp(self, i):
+        if i == 0:
+            self.buf.zero_()
         self.L.nig_clock_stamp(self.torch.cuda.current_stream().cuda_stream, self.buf[i].data_ptr())
 
     def read(self):
         import numpy as np
-        v = self.buf.cpu().numpy().astype(np.uint64).reshape(2, 8, 2)
-        mhz, span = [], []
-        for x in range(8):
-            (t0, r0), (t1, r1) = v[0, x], v[1, x]
-            if t0 and t1 and r1 > r0 and t1 > t0:
-                mhz.append(float(t1 - t0) / float(r1 - r0) * 100.0)
-                span.append(float(r1 - r0) / 1e5)
-        if not mhz:
-            return {"error": "no XCD stamped twice"}
-        mhz_sorted = sorted(mhz)
-        return {"shader_clock_mhz": mhz_sorted[len(mhz_sorted) // 2], "shader_clock_mhz_min": mhz_sorted[0], "shader_clock_mhz_max": mhz_sorted[-1],
-                "xcds": len(mhz), "span_ms": sorted(span)[len(span) // 2],
-                "how": "(s_memtime1 - s_memtime0) / (s_memrealtime1 - s_memrealtime0) x 100 MHz per XCD, median; stamps outside the timed interval"}
+        v = self.buf.cpu().numpy().astype(np.uint64).reshape(2, 2048, 2)
+        both = (v[0, :, 0] != 0) & (v[1, :, 0] != 0) & (v[1, :, 1] > v[0, :, 1]) & (v[1, :, 0] > v[0, :, 0])
+        if not both.any():
+            return {"error": "no compute unit stamped twice"}
+        dt = (v[1, both, 0] - v[0, both, 0]).astype(np.float64)
+        dr = (v[1, both, 1] - v[0, both, 1]).astype(np.float64)
+        mhz = np.sort(dt / dr * 100.0)
+        return {"shader_clock_mhz": float(np.median(mhz)), "shader_clock_mhz_p05": float(mhz[int(0.05 * (mhz.size - 1))]),
+                "shader_clock_mhz_p95": float(mhz[int(0.95 * (mhz.size - 1))]), "compute_units": int(mhz.size),
+                "span_ms": float(np.median(dr) / 1e5),
+                "how": "(s_memtime1 - s_memtime0) / (s_memrealtime1 - s_memrealtime0) x 100 MHz per compute unit stamped both times, "
+                       "median; the stamps are outside the timed interval"}
 
 
 _PROBE = None            # set by main() on a GPU run
@@ -387,6 +388,23 @@ def rollout_kernel_name(wl):
             return "rollout_pg_pair_kernel<%d>" % out
         return "rollout_wide_kernel<PowerGrid,%d,256>" % out
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
+
+
+def policy_kernel_name(ni, key, B, policy_kind="affine"):
+    """The kernel nig_rollout_policy launches for the whole 256-lane blocks of an auto-reset handle without frozen lanes
+    (csrc/nig_kernels.hpp launch_policy) -- since round 5 WHATEVER transition-stream outputs the call asks for: ChemicalReactor
+    in the three-wave closed-loop form (also in rounds), RobotAssembly in its BIG layout for a single round (the observation
+    rows ride in the producer -> integrator slot), PowerGrid's affine policies in the paired form with the register-resident
+    stepper (which writes the observation stream through the reset image); everything else on rollout_policy_kernel."""
+    blocks, per_round = B // 256, ni.tune()["split_blocks"]
+    last = blocks % per_round if per_round else 0
+    if key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):
+        return "split_policy_kernel<ChemicalReactor,4>"
+    if key == "ra" and blocks > 0 and per_round and blocks <= per_round:
+        return "split_policy_kernel<RobotAssembly,4>"
+    if key == "pg" and policy_kind == "affine" and blocks > 0 and per_round and blocks <= per_round:
+        return "rollout_pg_pair_policy_kernel<PolicyArgs> (pg_policy_reg_body)"
+    return "rollout_policy_kernel<%s>" % KERNEL_ENV[key]
 
 
 MALL_BYTES = 256 * 2**20      # Infinity Cache (MI355X_MICROARCH.md): FETCH_SIZE counts its hits, HBM does not serve them

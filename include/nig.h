@@ -172,12 +172,15 @@ int64_t nig_tune_get(int32_t key);
 int64_t nig_handle_tune_get(const nig_handle *h, int32_t key);
 
 /* Measurement aid (no counterpart upstream: performance_benchmark.py:106-133 times its loop with time.time()).  Enqueues a
- * 64-block kernel on `stream` of the CURRENT device that stamps, per XCD x (HW_REG_XCC_ID, 0-7), the shader-clock counter and
- * the constant 100 MHz counter into the caller's DEVICE buffer: out[2 x] = s_memtime, out[2 x + 1] = s_memrealtime (16 uint64;
- * an XCD no block landed on keeps its old words).  Two stamps around a run of launches give the clock the chip held over
- * that run: (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz, per XCD -- bench.py records it next to every timed
- * region so that box-to-box spread of a line can be attributed.  Never part of a timed kernel. */
-int nig_clock_stamp(void *stream, uint64_t *out16);
+ * small kernel on `stream` of the CURRENT device that stamps, per compute unit, the shader-clock counter and the constant
+ * 100 MHz counter into the caller's DEVICE buffer of NIG_CLOCK_STAMP_WORDS uint64: slot = XCD (HW_REG_XCC_ID, 0-7) x 256 +
+ * HW_REG_HW_ID bits 15:8 (se_id, sh_id, cu_id); out[2 slot] = s_memtime, out[2 slot + 1] = s_memrealtime; a compute unit no
+ * block landed on keeps its old words (zero the buffer first).  Two stamps around a run of launches give the clock the chip
+ * held over that run: (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz for every slot stamped both times --
+ * bench.py records the median next to every timed region so that box-to-box spread of a line can be attributed (VERDICT r04
+ * next #6).  Never part of a timed kernel. */
+#define NIG_CLOCK_STAMP_WORDS 4096
+int nig_clock_stamp(void *stream, uint64_t *out);
 
 /* utils.make registry lookup (utils.py:26-35): name -> id, or -1 */
 int nig_env_id(const char *name);

@@ -26,13 +26,17 @@ __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
 
-// nig_clock_stamp: one wave per block, enough blocks that the dispatcher's round robin reaches every XCD; blocks of one XCD
-// write the same pair of words with values a few hundred cycles apart (any of them will do)
+// nig_clock_stamp: one wave per block, many more blocks than compute units; a block stamps the slot of the compute unit it
+// runs on -- slot = XCD (HW_REG_XCC_ID) x 256 + HW_REG_HW_ID's {se_id, sh_id, cu_id} -- because s_memtime is NOT one counter per
+// chip (round 5, first attempt: per-XCD slots written by whichever block came last gave 2 030 .. 5 570 "MHz" across the XCDs of
+// one run).  Waves of one compute unit write the same pair of words with values a few cycles apart (any of them will do).
 __global__ void __launch_bounds__(64) clock_stamp_kernel(unsigned long long *o)
 {
     const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;      // HW_REG_XCC_ID (id 20), bits 3:0
-    if (threadIdx.x == 0) { o[2 * xcc] = t; o[2 * xcc + 1] = r; }
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;        // HW_REG_XCC_ID (id 20), bits 3:0
+    const unsigned cu = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 0xFFu;       // HW_REG_HW_ID (id 4), bits 15:8: cu_id, sh_id, se_id
+    const unsigned slot = xcc * 256u + cu;
+    if (threadIdx.x == 0) { o[2 * slot] = t; o[2 * slot + 1] = r; }
 }
 
 // n_total = the handle's enabled built-in constraints (3, 4 for AdvancedChemicalReactor, fewer after
@@ -362,10 +366,10 @@ int64_t nig_handle_tune_get(const nig_handle *h, int32_t key)
     return key == NIG_TUNE_SPLIT_BLOCKS ? (int64_t)nig::split_blocks_for(h->cus) : key == NIG_TUNE_WIDE_MIN_BLOCKS ? (int64_t)nig::wide_min_blocks_for(h->cus) : -1;
 }
 
-int nig_clock_stamp(void *stream, uint64_t *out16)
+int nig_clock_stamp(void *stream, uint64_t *out)
 {
-    if (!out16) return fail(NIG_ERR_INVALID, "nig_clock_stamp: NULL buffer%s");
-    hipLaunchKernelGGL(nig::clock_stamp_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out16);
+    if (!out) return fail(NIG_ERR_INVALID, "nig_clock_stamp: NULL buffer%s");
+    hipLaunchKernelGGL(nig::clock_stamp_kernel, dim3(4096), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out);
     HIP_TRY(hipGetLastError());
     return NIG_OK;
 }
@@ -791,11 +795,18 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
         for (int l = 0; l < 32; ++l) rec(1 + m2, r)[l] = b2[32 * m2 + l];
         ++r;
         for (int t = 0; t < 16; ++t, ++r)                     // head: rows i >= A are zero
-            for (int l = 0; l < 64; ++l)
-                if ((l & 31) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+            for (int l = 0; l < 64; ++l) {
+                if (A <= 4) {                                 // v_mfma_f32_4x4x1: lane 4 b + i of every 4-lane block holds head row i of ITS half's hidden row
+                    if ((l & 3) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 3)];
+                } else if ((l & 31) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+            }
         if (r != MLP_PER) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
     }
-    for (int l = 0; l < A; ++l) rec(MLP_MT, MLP_PER)[l] = b3[l];     // the head's bias rides at the end of the last chunk
+    if (A <= 4) {                                                    // the head's bias rides at the end of the last chunk
+        for (int l = 0; l < 64; ++l)
+            if ((l & 3) < A) rec(MLP_MT, MLP_PER)[l] = b3[l & 3];    // (4 x 4 x 1: every block's row lanes; B = 1 on lane half 0, 0 on half 1)
+    } else
+        for (int l = 0; l < A; ++l) rec(MLP_MT, MLP_PER)[l] = b3[l];
     hipError_t e = hipSuccess;
     if (!h->mlp_stream) e = hipMalloc((void **)&h->mlp_stream, (size_t)MLP_STREAM_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)MLP_STREAM_FLOATS * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);

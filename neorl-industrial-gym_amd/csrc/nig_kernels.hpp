@@ -1627,6 +1627,16 @@ typedef __attribute__((address_space(1))) const void nig_glb_void;
 // time (duty cycle 0.78, profiles/r04/mlp_cr65536_sq.txt).  An env with a couple of draws per step (KS <= 4) reads its table
 // entries from global memory (L2-resident, as step_kernel does) and the kernel is compiled for two waves per SIMD, so a second
 // block's waves fill the first's bubbles.
+// The head (layer 3) of an env with at most FOUR actions runs on v_mfma_f32_4x4x1_16B_f32 (round 5): sixteen 4 x 4 blocks of
+// four lanes, K = 1 -- lane l multiplies ITS OWN h2 value (B) with the four head weights held by the four lanes of its block
+// (A: lane 4 b + r holds W3[k][r]) into four accumulators, out[r] += W3[k][r] h2[k]: exactly a head of <= 4 rows, 8 cycles an
+// instruction, where the 32 x 32 x 2 tile spent 64 cycles on 32 rows of which 29 were zero padding (11 % of the step's MFMA
+// time).  Each lane half accumulates the hidden rows ITS accumulator registers hold (rho_h(t)), the two
+// partial sums meet in one v_add_f32 across the halves: a different summation order from the 32 x 32 x 2 head (k0, k1
+// interleaved), restated by the oracle (mlp_actor, A <= 4).
+template <class Env> constexpr bool mlp_head4 = Env::A <= 4;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <class Env> constexpr bool mlp_two_blocks = true;       // (PowerGrid's 23 + 31 table reads per step / reset from L2 as well: they are noise beside 1 217 MFMAs)
 
 template <class Env>
@@ -1703,6 +1713,7 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
         }
         gbuf ^= 1;
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        [[maybe_unused]] f32x4 out4 = {0, 0, 0, 0};          // mlp_head4: this lane half's partial sums of the (<= 4) head rows
         constexpr int RING = 8;                             // LDS reads in flight ahead of their MFMA (~64 cycles apart)
         for (int m2 = 0; m2 < MLP_MT; ++m2) {               // a real loop: the body is 145 MFMAs of straight-line code
             __syncthreads();                                // chunk 1 + m2 is in s_w[gbuf]; s_w[gbuf ^ 1] is free
@@ -1723,15 +1734,24 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, h1[i / 16][i % 16], acc, 0, 0, 0);
                 } else if (i == MLP_MT * 16) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, half ? 0.0f : 1.0f, acc, 0, 0, 0);      // + b2
-                } else {                               // this h2 tile is consumed at once by the head
+                } else if constexpr (mlp_head4<Env>) {  // this h2 tile is consumed at once by the head: 4 x 4 x 1, own value x the block's weights
+                    out4 = __builtin_amdgcn_mfma_f32_4x4x1f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out4, 0, 0, 0);
+                } else {
                     out = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (m2 + 1 == MLP_MT)                            // record 145 of the last chunk: + b3
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out, 0, 0, 0);
+            if (m2 + 1 == MLP_MT) {                          // record 145 of the last chunk: + b3
+                if constexpr (mlp_head4<Env>) out4 = __builtin_amdgcn_mfma_f32_4x4x1f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out4, 0, 0, 0);
+                else out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out, 0, 0, 0);
+            }
             gbuf ^= 1;
         }
+        if constexpr (mlp_head4<Env>) {
+            // action r = this half's partial sum + the other half's (lane l and l + 32 carry the same env)
+#pragma unroll
+            for (int r = 0; r < A; ++r) a[r] = det_tanhf(out4[r] + __shfl_xor(out4[r], 32));
+        } else {
         // action j sits in register j&3 of lane half j>>2: hand every lane all A of them
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1739,6 +1759,7 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
             const float other = __shfl_xor(mine, 32);
             if (r < A) a[r] = det_tanhf(half ? other : mine);
             if (r + 4 < A) a[r + 4] = det_tanhf(half ? mine : other);
+        }
         }
 
         // ---------------- IndustrialEnv.step (both lane halves, identical results) ----------------
@@ -2065,15 +2086,15 @@ static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
         // Producer / integrator / recorder wave per 64 lanes (nig_split_policy.hpp) for the batch's whole 256-lane blocks --
         // up to one block per CU, and (ChemicalReactor) larger batches in rounds under the rule of the open-loop rollout (the last
         // round at least 3/4 full) -- and the one-wave kernel for a ragged last block.  RobotAssembly (round 4: S = 24, the
-        // form's BIG layout): a single round only, as in the open loop, and not when the caller wants the observations of the
-        // transition stream (its I -> C slots carry no observation rows).
+        // form's BIG layout): a single round only, as in the open loop; the observations of the transition stream ride in its
+        // P -> I slots since round 5.
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
         const unsigned n_full = q.s.B / BLOCK, per_round = q.s.split_blocks;
         const unsigned last_round = per_round ? n_full % per_round : 0u;
         constexpr bool big = SplitPolicyLds<Env, BLOCK / 64>::BIG;
         const bool even_rounds = per_round != 0 && (n_full <= per_round ||
                                                     (!big && split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
-        if (plain && n_full > 0 && even_rounds && !(big && q.obs_out != nullptr)) {
+        if (plain && n_full > 0 && even_rounds) {
             PolicyArgs r = q;
             r.block0 = 0;
             hipLaunchKernelGGL((split_policy_kernel<Env, BLOCK / 64>), dim3(n_full), dim3(192 * (BLOCK / 64)), 0, st, r);

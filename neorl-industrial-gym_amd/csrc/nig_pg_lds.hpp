@@ -211,12 +211,17 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
     lt.clear();
 
     [[maybe_unused]] const float *ring = p.actions + base;
-    // ONE action register set: the action of step it + 1 is loaded into it as soon as step it has consumed its own
-    // (clip, generation update, the reward's action term: the first ~80 instructions of a step), i.e. a whole step
-    // (~1 200 instructions, four waves sharing the SIMD) before it is used.  The wait for it is in order with the stores
-    // issued before it -- those of step it - 1, long acknowledged by then.  (rollout_body keeps two to four sets: its
-    // envs' steps are shorter and run at one or two waves per SIMD.)
-    constexpr int DEPTH = 1;
+    // TWO action register sets (round 5): `buf[0]` holds the action of the step about to run, `buf[1]` receives the action of
+    // the step after it.  As soon as step it has consumed its action (clip, generation update, the reward's action term: the
+    // first ~80 instructions of a step) the set is renewed from buf[1] (eight v_mov) and the load for step it + 2 goes out.
+    // vmcnt counts loads and stores in ONE in-order queue on this architecture, so waiting for a load also waits for every
+    // store issued before it: with one set (rounds 3-4) the load of step it + 1 sat right behind the ten stores of step
+    // it - 1 and was waited for one step later -- and under a 5 TB/s write stream a store takes about that long to be
+    // acknowledged: a build whose actions come from a hash of lane and step instead of a load (NIG_DIAG_PG_NOACTLOAD) ran
+    // 1.96-1.98 ms per 250 steps against 2.13-2.24 (profiles/r05/pg_ab_s1.txt, full outputs; 1 % SLOWER without outputs).
+    // With two sets the stores a load waits behind are two steps old when it is needed.  (An unrolled-by-two loop with the sets
+    // swapping roles was tried in round 4: 128 registers + 24 spilled; the moves cost eight fast instructions per step.)
+    constexpr int DEPTH = 2;
     float buf[DEPTH][A];
     [[maybe_unused]] int slot = 0;
     if constexpr (!POLICY) slot = q.it0 % q.ring_len;
@@ -335,20 +340,6 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 for (int k = 0; k < 8; ++k) stream_store(obs_row + (9 + k) * q.ld_obs_out + tid, ngen[k]);
             }
             ngen7 = ngen[7];
-            // refill this action register set (step it + DEPTH), issued before the step's stores: see rollout_body
-            if constexpr (!POLICY) {
-#ifdef NIG_DIAG_PG_NOACTLOAD           // (diagnostic builds only, profiles/r05: no global load in the loop, hence no vmcnt wait that the
-            // step's stores could hold up -- the action is a cheap hash of lane and step instead; what is the in-order wait worth?)
-#pragma unroll
-            for (int k = 0; k < A; ++k)
-                abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
-#else
-#pragma unroll
-            for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
-            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-            act_next = (slot == 0) ? ring : act_next + q.slot_stride;
-#endif
-            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------
             [[maybe_unused]] const int itl = it - it0;                   // local step: the producer's slot index
@@ -507,6 +498,52 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // ---- renew the action sets (see DEPTH above): HERE, at the end of the step and right before its trajectory stores -- the
+            // load that is waited for went out a whole step ago, just before the PREVIOUS step's trajectory stores, so the stores it
+            // queues behind are those of two steps ago
+            if constexpr (!POLICY) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef NIG_DIAG_PG_NOACTLOAD           // (diagnostic builds only, profiles/r05: no global load in the loop, hence no vmcnt wait that the
+            // step's stores could hold up -- the action is a cheap hash of lane and step instead; what is the in-order wait worth?)
+#pragma unroll
+                for (int k = 0; k < A; ++k)
+                    abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+#elif defined(NIG_DIAG_PG_DEADLOAD)    // (diagnostic: the loads go out as usual but nothing in the loop reads them -- traffic without the wait)
+#pragma unroll
+                for (int k = 0; k < A; ++k)
+                    abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+                // (as inline asm into registers of their own: the compiler's wait-count pass does not see a load here, so nothing waits)
+#pragma unroll
+                for (int k = 0; k < A; ++k) asm volatile("global_load_dword %0, %1, off" : "+v"(buf[1][k]) : "v"(act_next + k * p.ld_act + tid));
+                slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+                act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+#else
+                // (the copy is an opaque instruction ON PURPOSE: as plain assignments hipcc rotates them over the loop's back edge to
+                // the top of the next step, in front of the load just issued -- and the wait lands on a load that is 40
+                // instructions old, behind stores that are one step old: the one-set timing again, with the load latency on top)
+#pragma unroll
+                for (int k = 0; k < A; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(abuf[k]) : "v"(buf[1][k]));   // the action of step it + 1 (its load went out a step ago)
+#ifdef NIG_DIAG_PG_ROWMAJOR_LOADS      // (diagnostic: the slot's [A][ld] block read as if it were [ld][A] -- two 16-byte loads per lane, 2 KiB
+                // contiguous per wave instead of eight 256-byte row segments; same bytes, same footprint, and since every entry is
+                // an independent uniform draw, the same workload statistically)
+                {
+                    const v4f *ap = reinterpret_cast<const v4f *>((act_next - base) + (size_t)(base + tid) * 8u);
+                    const v4f w0 = ap[0], w1 = ap[1];
+                    buf[1][0] = w0.x; buf[1][1] = w0.y; buf[1][2] = w0.z; buf[1][3] = w0.w;
+                    buf[1][4] = w1.x; buf[1][5] = w1.y; buf[1][6] = w1.z; buf[1][7] = w1.w;
+                }
+#elif defined(NIG_DIAG_PG_NTLOAD)      // (diagnostic: non-temporal action loads)
+#pragma unroll
+                for (int k = 0; k < A; ++k) buf[1][k] = __builtin_nontemporal_load(act_next + k * p.ld_act + tid);
+#else
+#pragma unroll
+                for (int k = 0; k < A; ++k) buf[1][k] = (act_next + k * p.ld_act)[tid];     // step it + 2
+#endif
+                slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+                act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (OUT == 3) {
                 // the image now holds the wave's 64 post-step rows: row-major float4 64 j + lane sits at 64 j + rd
                 v4f *oo = reinterpret_cast<v4f *>(obs_row);
@@ -586,6 +623,11 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
 #endif
     int it = it0;
     for (; it < q.n_steps; ++it) one_step(buf[0], it);
+#ifdef NIG_DIAG_PG_DEADLOAD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < A; ++k) asm volatile("" :: "v"(buf[1][k]));
+#endif
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const v4f v = mine[8 * g];
@@ -665,9 +707,21 @@ __device__ __forceinline__ void pg_policy_reg_body(const QA &q, const uint32_t b
     float *rew_row = p.reward ? p.reward + base : nullptr;
     uint32_t *fl_row = p.flags ? p.flags + base : nullptr;
     float *act_row = q.act_out ? q.act_out + base : nullptr;
+    // the observation the policy acts on, row-major [n_steps][B][S] (optional; round 5: this body writes it too -- through the
+    // wave's reset image, which is idle until the step's cooperative reset: the lane's eight float4 groups in the conflict-free
+    // layout of pg_lds_rollout_body's state image, read back transposed as eight 1 KiB whole-line streaming stores)
+    float *obs_row = q.obs_out ? q.obs_out + (size_t)(base + __builtin_amdgcn_readfirstlane(tid & ~63u)) * S : nullptr;
+    v4f *const timg = reinterpret_cast<v4f *>(s_img);
+    v4f *const mine = timg + (lane >> 3) * 64 + (lane & 7u);
+    const unsigned rd = (lane & 7u) * 8u + (lane >> 3);
     uint32_t seen = 0u;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int it = 0; it < q.n_steps; ++it) {
+        if (obs_row != nullptr) {                  // (wave-uniform) the lane's pre-step values into the image; read back transposed below,
+#pragma unroll                                     // behind the feedback law, so that the LDS round trip is not on this lone wave's chain
+            for (int g = 0; g < 8; ++g) { v4f w = {s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]}; mine[8 * g] = w; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // other lanes' rows are read below (compiler order; DS operations execute in order)
+        }
         if (seen < (uint32_t)it + 1u) seen = split_wait(nz_sync + 0, (uint32_t)it + 1u);
         const v4f *slot = nz_ring + (it & (PL::K - 1)) * PL::SLOT_V4 + lane;
         float z[24];
@@ -695,6 +749,17 @@ __device__ __forceinline__ void pg_policy_reg_body(const QA &q, const uint32_t b
 #pragma unroll
             for (int j = 0; j < A; ++j) stream_store(act_row + j * q.ld_act_out + tid, a[j]);
             act_row += q.act_step_stride;
+        }
+        if (obs_row != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4f tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tv[j] = timg[64 * j + rd];
+            v4f *oo = reinterpret_cast<v4f *>(obs_row);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stream_store(oo + lane + 64u * j, tv[j]);
+            obs_row += q.obs_step_stride;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the image is the cooperative reset's scratch later in the step
         }
         float nz[KS];
         Env::scale_step_normals(z, nz);
@@ -756,9 +821,11 @@ __global__ void __launch_bounds__(512, 2) rollout_pg_pair_policy_kernel(const QA
     if (wave >= 4u) pg_pair_producer<false, true, QA>(q, base, smem, wave - 4u, threadIdx.x & 63u);
 #ifdef NIG_DIAG_PG_POLICY_LDS          // (diagnostic builds only: the LDS-resident stepper for every call, for same-box A/Bs)
     else pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);
-#else
-    else if (q.obs_out != nullptr) pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);     // its image transposes the observation rows
+#elif defined(NIG_DIAG_PG_POLICY_LDS_OBS)   // (diagnostic: round 4's rule -- calls with the observation stream on the LDS-resident stepper)
+    else if (q.obs_out != nullptr) pg_lds_rollout_body<0, 256, true, false, true, QA>(q, base, smem);
     else pg_policy_reg_body<QA>(q, base, smem);
+#else
+    else pg_policy_reg_body<QA>(q, base, smem);    // (round 5: the register-resident stepper writes the observation stream as well)
 #endif
 }
 

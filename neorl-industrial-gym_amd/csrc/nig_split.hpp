@@ -296,7 +296,13 @@ __global__ void __launch_bounds__(192 * NP, 1) split_rollout_kernel(const Rollou
         split_post(sync + 2, (uint32_t)i + 1u, lane);          // (DS order: the reads above execute before this write)
         const int step_pre = (int)(ctr & NIG_CTR_STEP_MASK);
         StepResult<Env> res;
+#ifdef NIG_DIAG_SPLIT_REC_NOCOMPUTE    // (diagnostic builds only, profiles/r05: the recorder as a pure store wave -- no reward, penalties, flags or
+        // tally arithmetic, the same LDS reads and the same stores -- the upper bound of what a fourth, store-only wave per triple
+        // could give the headline; results are garbage)
+        res.reward = nx[0] + a[0]; res.terminated = false; res.truncated = false; res.nviol = (int)(vb & 1u); res.ncrit = 0; res.viol_bits = vb; res.shutdown = false;
+#else
         post_core<Env, float>(nx, a, vb, step_pre, p.max_steps, res);
+#endif
         const int step = step_pre + 1;
         const uint32_t viol_ep = (ctr >> NIG_CTR_VIOL_SHIFT) + (uint32_t)res.nviol;
         const bool done = res.terminated || res.truncated;

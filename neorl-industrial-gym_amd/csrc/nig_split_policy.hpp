@@ -18,12 +18,17 @@ namespace nig {
 
 template <class Env, int NP>
 struct SplitPolicyLds {
-    // BIG (S > 16: RobotAssembly, round 4): two ring slots instead of three, no observation rows in the I -> C slot (a launch
-    // that wants the transition stream's observations runs the one-wave kernel), and the feedback matrix as a dense LDS copy
-    // (policy_affine_dense) instead of registers -- what makes four triples of a 24-value state fit one CU's 160 KiB.
+    // BIG (S > 16: RobotAssembly, round 4): two ring slots instead of three, no observation rows in the I -> C slot, and the
+    // feedback matrix as a dense LDS copy (policy_affine_dense) instead of registers -- what makes four triples of a 24-value
+    // state fit one CU's 160 KiB.  The observation the policy acted on (the transition stream's `observations`, asked for at run
+    // time) travels in the P -> I slot instead (round 5): once the integrator has read the step's draws out of it, the slot is
+    // dead until the recorder releases it (the producer refills slot j only after the recorder is done with step j - K), so the
+    // integrator writes its 64 x S pre-step rows there and the recorder reads them transposed.  The slot has max(draw rows, S)
+    // rows for that: +2 rows, 4 KiB per block, 162 320 of 163 840 bytes.
     static constexpr bool BIG = Env::S > 16;
     static constexpr int K = BIG ? 2 : 3;                              // ring slots
-    static constexpr int HI_ROWS = Env::KS + 3 * Env::A + 1;           // noise, z, h, ra, wmix
+    static constexpr int DRAW_ROWS = Env::KS + 3 * Env::A + 1;         // noise, z, h, ra, wmix
+    static constexpr int HI_ROWS = (BIG && Env::S > DRAW_ROWS) ? Env::S : DRAW_ROWS;
     static constexpr int HI_SLOT = HI_ROWS * 64;                       // floats
     static constexpr int OBS_ROWS = BIG ? 0 : Env::S;                  // [64][S] observation acted on (for the transition stream)
     static constexpr int IH_SLOT = (OBS_ROWS + Env::S + 1 + Env::A) * 64;   // observation, [64][S] post-dynamics state, violation words, [A][64] action
@@ -195,6 +200,11 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
                 v4f *row = reinterpret_cast<v4f *>(ih) + lane * (S / 4);
 #pragma unroll
                 for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; row[k] = v; }
+            } else if (q.obs_out != nullptr) {     // BIG: the observation rows ride in the P -> I slot, whose draws are in registers by now
+                // (DS operations of a wave execute in order: the reads above precede these writes; wave-uniform switch)
+                v4f *row = reinterpret_cast<v4f *>(s_hi + slot * Lds::HI_SLOT) + lane * (S / 4);
+#pragma unroll
+                for (int k = 0; k < S / 4; ++k) { v4f v = {s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]}; row[k] = v; }
             }
 #pragma unroll
             for (int k = 0; k < A; ++k) ih[(OBS + S + 1 + k) * 64 + lane] = a[k];        // the policy's action, before the env's clip
@@ -248,15 +258,15 @@ __global__ void __launch_bounds__(192 * NP, 1) split_policy_kernel(const PolicyA
 #pragma unroll
         for (int k = 0; k < A; ++k) a[k] = ih[(OBS + S + 1 + k) * 64 + lane];
         [[maybe_unused]] v4f tr[S / 4];
-        if constexpr (OBS > 0) {
         if (q.obs_out) {                           // the wave's 64 observation rows in lane-contiguous order
+            // (written by the integrator before it posted this step: I -> C slot, or -- BIG -- the P -> I slot of the same index)
+            const v4f *src = OBS > 0 ? reinterpret_cast<const v4f *>(ih) : reinterpret_cast<const v4f *>(s_hi + cslot * Lds::HI_SLOT);
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) tr[k] = reinterpret_cast<const v4f *>(ih)[lane + 64u * k];
-        }
+            for (int k = 0; k < S / 4; ++k) tr[k] = src[lane + 64u * k];
         }
         split_post(sync + 2, (uint32_t)i + 1u, lane);
         const uint32_t orow = (uint32_t)i * q.out_stride;
-        if constexpr (OBS > 0) {
+        {
         if (q.obs_out) {
             v4f *oo = reinterpret_cast<v4f *>(q.obs_out + (size_t)i * q.obs_step_stride + (size_t)base * S);
 #pragma unroll

@@ -249,9 +249,15 @@ def test_powergrid_paired_closed_loop_equals_one_wave_form(ni, which, stream):
     laws power_grid.py:216-233 incl. the epsilon-mix with a uniform action, "MPC", constant, uniform random), with and
     without the transition stream, whole blocks + a ragged last block, three launches chained -- bit-identical to
     rollout_policy_kernel in rewards, flags, observations acted on, actions, final state, counters, returns, tallies.
-    A PID policy keeps the one-wave kernel (its memory lives in registers): same call, same results."""
+    A PID policy keeps the one-wave kernel (its memory lives in registers): same call, same results.
+    Round 5: with the observation stream ("transitions") the call STAYS on the paired form's register-resident stepper
+    (pg_policy_reg_body writes the rows through the wave's reset image); round 4 switched to the LDS-resident stepper for it."""
+    import bench
     S, A = 32, 8
     name = "PowerGrid-v0"
+    ni.tune(split_blocks=256)
+    assert bench.policy_kernel_name(ni, "pg", 1024, "pid" if which == "pid" else "affine") == (
+        "rollout_policy_kernel<PowerGrid>" if which == "pid" else "rollout_pg_pair_policy_kernel<PolicyArgs> (pg_policy_reg_body)")
     if which in ("expert", "medium", "random"):
         policy = ni.behaviour_policy(name, which)
     else:
@@ -271,9 +277,13 @@ def test_robot_assembly_three_wave_closed_loop_equals_one_wave_form(ni, which, s
     closed-loop form in its BIG layout (csrc/nig_split_policy.hpp: two ring slots, no observation rows in the I -> C slot, the
     feedback matrix prefetched from a dense LDS copy) -- get_dataset's behaviour laws (robot_assembly.py:266-290: feedback +
     uniform perturbations + epsilon-mix, clip to +-2), "MPC", constant, uniform random and PID (memory across launches) --
-    bit-identical to rollout_policy_kernel in rewards, flags, actions, final state, counters, returns, tallies, PID memory;
-    with the transition stream's observations requested the call stays on the one-wave kernel (same results by construction)."""
+    bit-identical to rollout_policy_kernel in rewards, flags, actions, final state, counters, returns, tallies, PID memory.
+    Round 5: the transition stream's OBSERVATIONS too -- they ride in the producer -> integrator slot once the integrator has
+    read the step's draws out of it (round 4 sent such calls to the one-wave kernel)."""
+    import bench
     S, A = 24, 7
+    ni.tune(split_blocks=256)
+    assert bench.policy_kernel_name(ni, "ra", 1024) == "split_policy_kernel<RobotAssembly,4>"       # for every stream mode
     if which in ("expert", "medium", "random"):
         policy = ni.behaviour_policy(RA, which)
     else:
