@@ -532,10 +532,13 @@ struct PowerGrid {
     }
     __device__ static double reward_econ(const float (&g)[8])                            // :169-170 int64 * float32 -> float64
     {
-        double cg[8];
+        // np.sum's pairwise tree over the eight float64 products ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  A product
+        // cost x generation is EXACT in float64 (a 6-bit integer times a 24-bit significand), so p_even + p_odd is one fused
+        // multiply-add with the same single rounding: four v_fma_f64 for four multiplies + four adds (round 5; same bits)
+        double pr[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cg[i] = gen_cost(i) * (double)g[i];
-        return ddiv_y(-sum8(cg), 1000.0, 1.0 / 1000.0);
+        for (int i = 0; i < 4; ++i) pr[i] = __builtin_fma(gen_cost(2 * i + 1), (double)g[2 * i + 1], gen_cost(2 * i) * (double)g[2 * i]);
+        return ddiv_y(-((pr[0] + pr[1]) + (pr[2] + pr[3])), 1000.0, 1.0 / 1000.0);
     }
     __device__ static float reward_act(const float (&a)[A])                              // :173
     {

@@ -211,17 +211,17 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
     lt.clear();
 
     [[maybe_unused]] const float *ring = p.actions + base;
-    // TWO action register sets (round 5): `buf[0]` holds the action of the step about to run, `buf[1]` receives the action of
-    // the step after it.  As soon as step it has consumed its action (clip, generation update, the reward's action term: the
-    // first ~80 instructions of a step) the set is renewed from buf[1] (eight v_mov) and the load for step it + 2 goes out.
-    // vmcnt counts loads and stores in ONE in-order queue on this architecture, so waiting for a load also waits for every
-    // store issued before it: with one set (rounds 3-4) the load of step it + 1 sat right behind the ten stores of step
-    // it - 1 and was waited for one step later -- and under a 5 TB/s write stream a store takes about that long to be
-    // acknowledged: a build whose actions come from a hash of lane and step instead of a load (NIG_DIAG_PG_NOACTLOAD) ran
-    // 1.96-1.98 ms per 250 steps against 2.13-2.24 (profiles/r05/pg_ab_s1.txt, full outputs; 1 % SLOWER without outputs).
-    // With two sets the stores a load waits behind are two steps old when it is needed.  (An unrolled-by-two loop with the sets
-    // swapping roles was tried in round 4: 128 registers + 24 spilled; the moves cost eight fast instructions per step.)
-    constexpr int DEPTH = 2;
+    // ONE action register set: the action of step it + 1 is loaded into it as soon as step it has consumed its own
+    // (clip, generation update, the reward's action term: the first ~80 instructions of a step), i.e. a whole step
+    // (~1 200 instructions, four waves sharing the SIMD) before it is used.  The wait for it is in order with the stores
+    // issued before it -- those of step it - 1.  Round 5 asked whether that in-order wait is what the action reads cost
+    // with full outputs (a build without the loads ran 1.96-1.98 ms per 250 steps against 2.11-2.27): it is NOT.  Two
+    // register sets with the copy pinned at the end of the step (the stores a load queues behind are then two steps old)
+    // changed nothing (2 270 / 2 274 vs 2 275 / 2 244 us), loads that go out but are never waited for are no faster than
+    // the real ones (2 150 vs 2 110 us), and an action ring that fits the 256 MB Infinity Cache gives the no-load time
+    // (1 976 us): what costs is READ TRAFFIC REACHING HBM inside a 4.5 TB/s write stream, not the wave's wait
+    // (profiles/r05/pg_ab_s2_two_action_sets.txt, pg_ab_s3_action_read_cost.txt).
+    constexpr int DEPTH = 1;
     float buf[DEPTH][A];
     [[maybe_unused]] int slot = 0;
     if constexpr (!POLICY) slot = q.it0 % q.ring_len;
@@ -318,7 +318,14 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float g = s[9 + i] + a[i];                                   // power_grid.py:124 np.clip(gen + a, 0, 100)
-                g = (g < 0.0f) ? 0.0f : g;
+                // lower bound: np.maximum(g, 0) keeps a NaN and keeps -0.0 (it returns its first argument on a tie).  The generator-
+                // driven path takes v_maximum3_f32 (IEEE-754-2019 maximum: keeps the NaN, returns +0.0 for -0.0) -- one instruction
+                // for compare + select; it differs from NumPy only on an input of exactly -0.0, which this arithmetic cannot
+                // produce from non-negative generation and a finite action (x + y = -0.0 needs both -0.0) -- only nig_set_state
+                // can plant one, and the difference is the sign of a zero in that step's stored value.  Recorded-draw launches
+                // (NOISE: the parity path through this body) keep the compare + select.
+                if constexpr (NOISE) g = (g < 0.0f) ? 0.0f : g;
+                else g = __builtin_elementwise_maximum(g, 0.0f);
                 g = __builtin_elementwise_minimum(g, 100.0f);      // np.minimum incl. NaN: one v_minimum3_f32 (nig_envs.hpp dynamics)
                 ngen[i] = g;
                 load[i] = s[17 + i];
@@ -340,6 +347,31 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 for (int k = 0; k < 8; ++k) stream_store(obs_row + (9 + k) * q.ld_obs_out + tid, ngen[k]);
             }
             ngen7 = ngen[7];
+            // refill this action register set (step it + DEPTH), issued before the step's stores: see rollout_body
+            if constexpr (!POLICY) {
+#ifdef NIG_DIAG_PG_NOACTLOAD           // (diagnostic builds only, profiles/r05: no global load in the loop -- the action is a cheap hash of lane
+            // and step instead; what do the action reads cost?)
+#pragma unroll
+            for (int k = 0; k < A; ++k)
+                abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+#elif defined(NIG_DIAG_PG_ROWMAJOR_LOADS)  // (diagnostic: the slot's [A][ld] block read as if it were [ld][A] -- two 16-byte loads per lane, 2 KiB
+            // contiguous per wave instead of eight 256-byte row segments; same bytes, same footprint, and since every entry is an
+            // independent uniform draw, the same workload statistically: -1 % with full outputs, profiles/r05/pg_ab_s4_rowmajor_ntload.txt)
+            {
+                const v4f *ap = reinterpret_cast<const v4f *>((act_next - base) + (size_t)(base + tid) * 8u);
+                const v4f w0 = ap[0], w1 = ap[1];
+                abuf[0] = w0.x; abuf[1] = w0.y; abuf[2] = w0.z; abuf[3] = w0.w;
+                abuf[4] = w1.x; abuf[5] = w1.y; abuf[6] = w1.z; abuf[7] = w1.w;
+            }
+            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+            act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+#else
+#pragma unroll
+            for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
+            slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
+            act_next = (slot == 0) ? ring : act_next + q.slot_stride;
+#endif
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- voltages: generator blocks 0 and 1 of the step stream (draw_step: z[0..7], sd 0.005) ---------------
             [[maybe_unused]] const int itl = it - it0;                   // local step: the producer's slot index
@@ -445,7 +477,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                 // one random-walk update: load rows (:140-141, clipped at 0) and line-flow rows (:144, sd 2.0)
                 auto walk_load = [&](float h, int c) __attribute__((always_inline)) -> float {
                     if constexpr (NOISE) { double l = (double)h + zd[c]; l = (l < 0.0) ? 0.0 : l; return (float)l; }
-                    else { const float l = h + zn(c); return (l < 0.0f) ? 0.0f : l; }
+                    else return __builtin_elementwise_maximum(h + zn(c), 0.0f);      // (v_maximum3_f32, as the generation clip above: h >= +0, z != 0)
                 };
                 auto walk_flow = [&](float h, int c) __attribute__((always_inline)) -> float {
                     if constexpr (NOISE) return (float)((double)h + zd[c]);
@@ -496,52 +528,6 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
                         for (int c = 0; c < 3; ++c) stream_store(obs_row + (29 + c) * q.ld_obs_out + tid, fl[c]);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- renew the action sets (see DEPTH above): HERE, at the end of the step and right before its trajectory stores -- the
-            // load that is waited for went out a whole step ago, just before the PREVIOUS step's trajectory stores, so the stores it
-            // queues behind are those of two steps ago
-            if constexpr (!POLICY) {
-                __builtin_amdgcn_sched_barrier(0);
-#ifdef NIG_DIAG_PG_NOACTLOAD           // (diagnostic builds only, profiles/r05: no global load in the loop, hence no vmcnt wait that the
-            // step's stores could hold up -- the action is a cheap hash of lane and step instead; what is the in-order wait worth?)
-#pragma unroll
-                for (int k = 0; k < A; ++k)
-                    abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
-#elif defined(NIG_DIAG_PG_DEADLOAD)    // (diagnostic: the loads go out as usual but nothing in the loop reads them -- traffic without the wait)
-#pragma unroll
-                for (int k = 0; k < A; ++k)
-                    abuf[k] = (float)((((uint32_t)gi + 0x9E3779B9u * (uint32_t)(it + k)) * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f;
-                // (as inline asm into registers of their own: the compiler's wait-count pass does not see a load here, so nothing waits)
-#pragma unroll
-                for (int k = 0; k < A; ++k) asm volatile("global_load_dword %0, %1, off" : "+v"(buf[1][k]) : "v"(act_next + k * p.ld_act + tid));
-                slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-                act_next = (slot == 0) ? ring : act_next + q.slot_stride;
-#else
-                // (the copy is an opaque instruction ON PURPOSE: as plain assignments hipcc rotates them over the loop's back edge to
-                // the top of the next step, in front of the load just issued -- and the wait lands on a load that is 40
-                // instructions old, behind stores that are one step old: the one-set timing again, with the load latency on top)
-#pragma unroll
-                for (int k = 0; k < A; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(abuf[k]) : "v"(buf[1][k]));   // the action of step it + 1 (its load went out a step ago)
-#ifdef NIG_DIAG_PG_ROWMAJOR_LOADS      // (diagnostic: the slot's [A][ld] block read as if it were [ld][A] -- two 16-byte loads per lane, 2 KiB
-                // contiguous per wave instead of eight 256-byte row segments; same bytes, same footprint, and since every entry is
-                // an independent uniform draw, the same workload statistically)
-                {
-                    const v4f *ap = reinterpret_cast<const v4f *>((act_next - base) + (size_t)(base + tid) * 8u);
-                    const v4f w0 = ap[0], w1 = ap[1];
-                    buf[1][0] = w0.x; buf[1][1] = w0.y; buf[1][2] = w0.z; buf[1][3] = w0.w;
-                    buf[1][4] = w1.x; buf[1][5] = w1.y; buf[1][6] = w1.z; buf[1][7] = w1.w;
-                }
-#elif defined(NIG_DIAG_PG_NTLOAD)      // (diagnostic: non-temporal action loads)
-#pragma unroll
-                for (int k = 0; k < A; ++k) buf[1][k] = __builtin_nontemporal_load(act_next + k * p.ld_act + tid);
-#else
-#pragma unroll
-                for (int k = 0; k < A; ++k) buf[1][k] = (act_next + k * p.ld_act)[tid];     // step it + 2
-#endif
-                slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
-                act_next = (slot == 0) ? ring : act_next + q.slot_stride;
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (OUT == 3) {
@@ -623,11 +609,6 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
 #endif
     int it = it0;
     for (; it < q.n_steps; ++it) one_step(buf[0], it);
-#ifdef NIG_DIAG_PG_DEADLOAD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < A; ++k) asm volatile("" :: "v"(buf[1][k]));
-#endif
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const v4f v = mine[8 * g];
