@@ -373,7 +373,8 @@ def rollout_kernel_name(wl):
     out = {"none": 0, "min": 1, "full": 3}[wl.outputs]
     blocks, per_round = wl.B // 256, wl.ni.tune()["split_blocks"]
     last = blocks % per_round if per_round else 0
-    if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):   # (+ a one-wave launch for a ragged last block)
+    # (+ a one-wave launch for a ragged last block; beyond one round only for launches that write the observation trajectory, round 5)
+    if wl.key == "cr" and blocks > 0 and per_round and (blocks <= per_round or (out >= 2 and (last == 0 or 4 * last >= 3 * per_round))):
         return "split_rollout_kernel<ChemicalReactor,%d,4>" % out
     if wl.key == "ra" and blocks > 0 and per_round and blocks <= per_round:     # RobotAssembly: the three-wave form for one round only
         return "split_rollout_kernel<RobotAssembly,%d,4>" % out
@@ -390,15 +391,15 @@ def rollout_kernel_name(wl):
     return "rollout_kernel<%s,%d>" % (KERNEL_ENV[wl.key], out)
 
 
-def policy_kernel_name(ni, key, B, policy_kind="affine"):
+def policy_kernel_name(ni, key, B, policy_kind="affine", stream_obs=True):
     """The kernel nig_rollout_policy launches for the whole 256-lane blocks of an auto-reset handle without frozen lanes
     (csrc/nig_kernels.hpp launch_policy) -- since round 5 WHATEVER transition-stream outputs the call asks for: ChemicalReactor
-    in the three-wave closed-loop form (also in rounds), RobotAssembly in its BIG layout for a single round (the observation
+    in the three-wave closed-loop form (a second round only with the observation stream, never more), RobotAssembly in its BIG layout for a single round (the observation
     rows ride in the producer -> integrator slot), PowerGrid's affine policies in the paired form with the register-resident
     stepper (which writes the observation stream through the reset image); everything else on rollout_policy_kernel."""
     blocks, per_round = B // 256, ni.tune()["split_blocks"]
     last = blocks % per_round if per_round else 0
-    if key == "cr" and blocks > 0 and per_round and (blocks <= per_round or last == 0 or 4 * last >= 3 * per_round):
+    if key == "cr" and blocks > 0 and per_round and (blocks <= per_round or (stream_obs and blocks <= 2 * per_round and (last == 0 or 4 * last >= 3 * per_round))):
         return "split_policy_kernel<ChemicalReactor,4>"
     if key == "ra" and blocks > 0 and per_round and blocks <= per_round:
         return "split_policy_kernel<RobotAssembly,4>"

@@ -146,7 +146,9 @@ const char *nig_last_error(void);
  *                           device, read at nig_create (256 on an MI355X; nig_tune_get reports it for the device of
  *                           the latest handle), 0 = never use that form.  An explicit value is process-wide and atomic.  nig_rollout
  *                           uses it for batches of at most one round and (ChemicalReactor) for larger ones whose
- *                           last round is at least 3/4 full, nig_rollout_policy (ChemicalReactor) likewise.  The same
+ *                           last round is at least 3/4 full WHEN the launch writes an observation trajectory (without one the
+ *                           rounds lose to lanes filling the SIMDs, measured in round 5), nig_rollout_policy (ChemicalReactor)
+ *                           likewise.  The same
  *                           "one wave per SIMD" threshold selects PowerGrid's paired rollout form (a producer wave per
  *                           stepping wave, csrc/nig_pg_lds.hpp) and the step kernel's helper waves (nig_step / nig_plan_*
  *                           on auto-reset handles of ChemicalReactor, PowerGrid, RobotAssembly).  The environment variable

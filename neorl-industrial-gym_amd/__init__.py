@@ -38,7 +38,7 @@ def tune(split_blocks=None, wide_min_blocks=None):
             "wide_min_blocks": int(L.nig_tune_get(_lib.TUNE_WIDE_MIN_BLOCKS))}
 
 
-__version__ = "0.4.0"        # generator "nig-philox-v3" since round 4 (v2 + PowerGrid's reset load factors from spare low bytes; libnig: nig_version())
+__version__ = "0.5.0"        # generator "nig-philox-v3" since round 4 (v2 + PowerGrid's reset load factors from spare low bytes; libnig: nig_version())
 GENERATOR = "nig-philox-v3"
 __all__ = [
     "__version__", "DatasetQuality", "SafetyConstraint", "SafetyMetrics", "IndustrialEnv",

@@ -335,7 +335,12 @@ extern "C" {
 // from the first auto-reset on; ChemicalReactor, RobotAssembly and every other env are bit-identical to v2.
 // 0.4.0 (round 4): generator unchanged for the reference's envs; the four build-specified plants moved to their model "v2"
 // (spec_plants.py: fused multiply-adds, steps 2k-1 / 2k sharing one generator block) -- their trajectories differ from 0.3.0's.
-const char *nig_version(void) { return "nig 0.4.0 (gfx950; generator nig-philox-v3)"; }
+// 0.5.0 (round 5): generator unchanged -- every fast-mode trajectory of 0.4.0 replays bit for bit (the generator's piece index and
+// PowerGrid's clips / economic sum are computed with fewer instructions, same values).  Changed results: nig_rollout_mlp for envs
+// with at most four actions (ChemicalReactor, WaterTreatment) sums the head in the order of its v_mfma_f32_4x4x1 form (last-bit
+// differences in the action against 0.4.0; the oracle restates the new order).  New entry point: nig_clock_stamp.  A caller
+// workspace is refused only when positively identified as host / managed / foreign-device memory.
+const char *nig_version(void) { return "nig 0.5.0 (gfx950; generator nig-philox-v3)"; }
 const char *nig_last_error(void) { return g_err; }
 
 int nig_tune(int32_t key, int64_t value)

@@ -1972,11 +1972,18 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
         // form in ROUNDS of one block per CU, which beats the one-wave form (lanes filling the SIMDs) by 4-12 % when
         // the rounds come out even -- measured at 2, 3, 4, 8 and 16 rounds, profiles/r02/rounds_probe.txt -- and loses
         // when the last round is mostly empty (1.5 rounds: -8 %): used when the last round is at least 3/4 full.
+        // Round 5: ... and only for launches that write an observation trajectory (out_mode >= 2).  A round takes the three-wave
+        // pipeline's ~142 us per 250 steps whatever it writes, so with reward + flags or no outputs the rounds LOSE to lanes
+        // filling the SIMDs -- 131 072 lanes 280 vs 214-231 us, 262 144 lanes 555 vs 384-409 us, 1 048 576 lanes 2.20 vs
+        // 1.31-1.46 ms -- while with the trajectory (HBM-bound either way) they win by 6-15 % (335 vs 378 us, 680 vs 726 us,
+        // 3.30 vs 3.72 ms; profiles/r05/cr_rounds_by_output_mode.txt).  Found by the mixed-launch floor table, whose
+        // stand-alone ChemicalReactor column was slower than the same body inside the mixed kernel.
         const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
         const unsigned per_round = q.s.split_blocks;       // nig_tune(NIG_TUNE_SPLIT_BLOCKS), default: the device's compute units
         const unsigned last_round = per_round ? n_full % per_round : 0u;
         const bool even_rounds = per_round != 0 && (n_full <= per_round ||
-                                                    (split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
+                                                    (split_rounds<Env>::value && (out_mode >= 2 || NOISE) &&
+                                                     (last_round == 0 || 4u * last_round >= 3u * per_round)));
         if (plain && n_full > 0 && even_rounds) {
             r.block0 = 0;
             launch_split_blocks<Env, BLOCK / 64, NOISE>(out_mode, r, n_full, st);
@@ -2092,8 +2099,13 @@ static void launch_policy(const PolicyArgs &q, unsigned grid, hipStream_t st)
         const unsigned n_full = q.s.B / BLOCK, per_round = q.s.split_blocks;
         const unsigned last_round = per_round ? n_full % per_round : 0u;
         constexpr bool big = SplitPolicyLds<Env, BLOCK / 64>::BIG;
+        // (beyond one round only for calls that write the observation stream, as in the open loop, and only up to TWO rounds:
+        // a closed-loop round takes ~1 us per step whatever it writes, lanes filling the SIMDs take 1.75 / 2.5 us per step at
+        // 131 072 / 262 144 lanes without the stream and 1.97 / 3.25 with it -- two rounds 1.84, four rounds 3.72:
+        // profiles/r05/policy_rounds_cr.txt)
         const bool even_rounds = per_round != 0 && (n_full <= per_round ||
-                                                    (!big && split_rounds<Env>::value && (last_round == 0 || 4u * last_round >= 3u * per_round)));
+                                                    (!big && split_rounds<Env>::value && q.obs_out != nullptr && n_full <= 2u * per_round &&
+                                                     (last_round == 0 || 4u * last_round >= 3u * per_round)));
         if (plain && n_full > 0 && even_rounds) {
             PolicyArgs r = q;
             r.block0 = 0;

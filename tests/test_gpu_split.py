@@ -226,12 +226,17 @@ def test_split_policy_form_equals_one_wave_form(ni, which, stream):
     _same(a, b)
 
 
-@pytest.mark.parametrize("B,split_blocks", [(1024 + 100, 256), (256 + 1, 256), (5 * 256, 2), (8 * 256 + 77, 4), (7 * 256, 4)])
+@pytest.mark.parametrize("B,split_blocks", [(1024 + 100, 256), (256 + 1, 256), (4 * 256, 2), (5 * 256, 2), (8 * 256 + 77, 4), (7 * 256, 4)])
 def test_split_policy_form_with_a_ragged_tail_and_in_rounds(ni, B, split_blocks):
     """Round 3: the closed loop's whole 256-lane blocks run the three-wave form and a ragged last block the one-wave
     kernel (one call, two launches); batches of several rounds (here: rounds of 2 or 4 blocks) run it in rounds when the
-    last round is at least 3/4 full ((5 blocks, 2 per round) and (7, 4): yes; (8 + tail, 4): even) -- all bit-identical
-    to the one-wave kernel, PID memory and transition stream included."""
+    last round is at least 3/4 full ((4 blocks, 2 per round) and (8 + tail, 4): even; (7, 4): yes) -- since round 5 at most TWO
+    rounds and only with the observation stream (three rounds, (5, 2), stay on the one-wave kernel: measured slower in rounds,
+    profiles/r05/policy_rounds_cr.txt) -- all bit-identical to the one-wave kernel, PID memory and transition stream included."""
+    import bench
+    ni.tune(split_blocks=split_blocks)
+    expect_split = B // 256 <= 2 * split_blocks
+    assert bench.policy_kernel_name(ni, "cr", B).startswith("split_policy_kernel") == expect_split
     for policy in (ni.behaviour_policy(NAME, "medium"), ni.pid_agent(12, 3)):
         kw = dict(policy=policy, B=B, chunks=[7, 6], stream="transitions", max_steps=9)
         ni.tune(split_blocks=split_blocks)

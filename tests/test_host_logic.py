@@ -322,7 +322,8 @@ def test_bench_names_the_kernel_the_library_launches():
         assert name("cr", 65536) == "split_rollout_kernel<ChemicalReactor,3,4>"
         assert name("cr", 65536, "none") == "split_rollout_kernel<ChemicalReactor,0,4>"
         assert name("cr", 1024, "min") == "split_rollout_kernel<ChemicalReactor,1,4>"
-        assert name("cr", 131072).startswith("split_") and name("cr", 1048576).startswith("split_")   # even rounds
+        assert name("cr", 131072).startswith("split_") and name("cr", 1048576).startswith("split_")   # even rounds, with the trajectory
+        assert name("cr", 131072, "min").startswith("rollout_kernel<") and name("cr", 1048576, "none").startswith("rollout_kernel<")   # round 5: rounds lose without it
         assert name("cr", 65536 + 49152 + 256).startswith("split_")                                   # last round 193 / 256 blocks
         assert name("cr", 98304).startswith("rollout_kernel<")                                        # 1.5 rounds
         assert name("cr", 65536 + 100).startswith("split_")          # whole blocks in this form, the ragged last block in a one-wave launch
