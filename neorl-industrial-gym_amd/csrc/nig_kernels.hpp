@@ -1991,6 +1991,10 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
             return;
         }
     }
+    // (Round 5 tried the three-wave form for the LAST, partial residency round of a RobotAssembly batch -- 262 144 lanes = 768 blocks
+    // one-wave + 256 three-wave, two launches -- on the idea that those blocks run one to a compute unit anyway: slower, full outputs
+    // 1 857-1 877 vs 1 842-1 863 us, reward + flags 1 590 vs 1 464, none 1 559 vs 1 427 (profiles/r05/ra_tail_round_three_wave_ab.txt):
+    // one launch lets the tail's blocks start as compute units free up, two launches drain the chip in between.  Not kept.)
     unsigned first = 0;                            // first 256-lane block the forms below still have to run
     if constexpr (!PAIRED && wide_rollout<Env>::value != 0) {
         // Envs with an LDS-resident rollout body (PowerGrid, nig_pg_lds.hpp), handles on which no lane can be frozen:

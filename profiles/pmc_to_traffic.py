@@ -75,6 +75,14 @@ def main():
         allt = json.load(open(tpath))
     except Exception:
         allt = {}
+    group = [k for k in summary if re.search(want, k)]
+    if len(group) > 1 and len({summary[k]["detail"]["FETCH_SIZE"]["n"] for k in group}) == 1:
+        # one bench step = several kernels of this env launched back to back (RobotAssembly beyond one residency round: the full
+        # rounds one-wave + the tail three-wave): their bytes add up to the launch's
+        tot = {f: sum(summary[k][f] for k in group) for f in ("hbm_bytes_per_launch", "fetch_bytes", "write_bytes")}
+        k0 = group[0]
+        summary = {" + ".join(group): dict(summary[k0], kernel=" + ".join(group), hbm_bytes_per_env_step=tot["hbm_bytes_per_launch"] / (B * P),
+                                           env_steps_per_launch=B * P, **tot)}
     for k, v in summary.items():
         if re.search(want, k):
             rec = {kk: vv for kk, vv in v.items() if kk != "detail"}
