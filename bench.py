@@ -450,6 +450,7 @@ def roofline_of(wl, K, dev_ms):
             "hbm_side_model": why,
             "traffic": None if per_step is None else per_step * env_steps_per_kernel,
             "traffic_bytes_per_env_step": per_step, "traffic_source": src,
+            "traffic_measured_in_this_run": False,      # looked up from the committed PMC passes of the same kernel and launch shape (profiles/traffic.json)
             "kernel": (rollout_kernel_name(wl) if rollout else "step_kernel<%s,false>" % KERNEL_ENV[wl.key]),
             "alg_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_kernel,
             "alg_bytes_per_launch": alg, "launch_us": kernel_us, "launches_timed": n_kernels,

@@ -45,6 +45,19 @@ __device__ __forceinline__ void store16(float *dst16, float a, float b, float c,
 template <class T>
 __device__ __forceinline__ void stream_store(T *dst, T v)
 {
+#ifdef NIG_DIAG_STORE_POLICY           // (diagnostic builds only, profiles/r05: another cache policy for the 16-byte trajectory stores --
+    // 1 = sc1 (write-through, dropped from L2), 2 = sc0 sc1, 3 = nt sc1; the production nt keeps the line in L2)
+    if constexpr (sizeof(T) == 16) {
+#if NIG_DIAG_STORE_POLICY == 1
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+#elif NIG_DIAG_STORE_POLICY == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+#else
+        asm volatile("global_store_dwordx4 %0, %1, off nt sc1" :: "v"(dst), "v"(v) : "memory");
+#endif
+        return;
+    }
+#endif
     __builtin_nontemporal_store(v, dst);
 }
 constexpr int REDUCE_BLOCKS = 256;

@@ -876,49 +876,61 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "info":
     gen_info()
 
 
-STATS_EPISODES = {"cr": 6000, "pg": 40000, "ra": 40000}
+STATS_EPISODES = {"cr": 24000, "pg": 160000, "ra": 160000}
+
+
+def _stats_env(key):
+    """One env's share of gen_stats (a process of its own: the reference's draws are module-global np.random state)."""
+    utils = load_reference()
+    name = ENVS[key]
+    env = utils.make(name)
+    A = env.action_dim
+    n = STATS_EPISODES[key]
+    np.random.seed(20250 + ord(key[0]))                         # the reference's own generator, its own call order
+    arng = np.random.Generator(np.random.PCG64(7 + ord(key[1])))  # action_space.sample(): gymnasium draws from its own stream
+    length = np.zeros(n, np.int32); ret = np.zeros(n); viol = np.zeros(n, np.int32); crit = np.zeros(n, np.int32)
+    cbits = np.zeros((n, 3), np.int32); cause = np.zeros(n, np.uint8)
+    for e in range(n):
+        env.reset()
+        R, T, ncrit = 0.0, 0, 0
+        while True:
+            a = arng.uniform(-1.0, 1.0, A).astype(f32)
+            bits = constraint_bits(env, env.state, a)          # the reference's own check_fn on the pre-step state
+            obs, reward, term, trunc, info = env.step(a)
+            sm = info["safety_metrics"]
+            assert sm.violation_count == 3 - sum(bits)
+            R += float(reward); T += 1; ncrit += sm.critical_violations
+            for k in range(3):
+                cbits[e, k] += 1 - bits[k]
+            if term or trunc:
+                break
+        length[e], ret[e], viol[e], crit[e] = T, R, info["violations"], ncrit
+        cause[e] = (1 if term else 0) | (2 if trunc else 0) | (4 if info["critical_shutdown"] else 0)
+    print(key, n, "episodes: length mean %.2f median %d max %d | viol/ep %.3f crit/ep %.4f | ret mean %.2f | term %.4f trunc %.4f shutdown %.4f"
+          % (length.mean(), np.median(length), length.max(), viol.mean(), crit.mean(), ret.mean(),
+             (cause & 1).astype(bool).mean(), (cause & 2).astype(bool).mean(), (cause & 4).astype(bool).mean()), flush=True)
+    # compact dtypes: lengths <= 1000, counts <= 3000, returns to float32 (the statistics are means over thousands of episodes)
+    assert length.max() <= 65535 and viol.max() <= 65535 and cbits.max() <= 65535 and crit.max() <= 255
+    return {f"{key}_length": length.astype(np.uint16), f"{key}_ret": ret.astype(np.float32), f"{key}_viol": viol.astype(np.uint16),
+            f"{key}_crit": crit.astype(np.uint8), f"{key}_cbits": cbits.astype(np.uint16), f"{key}_cause": cause}
 
 
 def gen_stats():
     """The workload the driver times, run by the REFERENCE: performance_benchmark.py:106-133's loop (uniform float32
     actions in [-1, 1] = action_space.sample(), reset when terminated or truncated) with the reference's own
     np.random draws (chemical_reactor.py:93-103,149,159, power_grid.py:98-108,136-144, robot_assembly.py:118-122;
-    MT19937 seeded per env below).  Stored PER EPISODE, so a test can form any statistic and its sampling error:
-      length, ret (sum of rewards, float64), viol (info['violations'] at the end = sum of per-step violation counts,
+    MT19937 seeded per env).  Stored PER EPISODE, so a test can form any statistic and its sampling error:
+      length, ret (sum of rewards), viol (info['violations'] at the end = sum of per-step violation counts,
       base.py:179-183), crit (sum of per-step critical_violations), cbits [3] (steps on which constraint k failed),
       cause (bit 0 terminated, bit 1 truncated, bit 2 critical shutdown: the last step's flags, base.py:186-196).
     Nothing here depends on this build: the fast-mode generator of the device path has to reproduce these
-    DISTRIBUTIONS (tests/test_gpu_reference_stats.py, bench.py's parity block)."""
-    utils = load_reference()
+    DISTRIBUTIONS (tests/test_reference_stats.py, tests/test_gpu_reference_stats.py, bench.py's parity block).
+    Round 5 grew the sample fourfold (24 000 / 160 000 / 160 000 episodes: standard errors halve); one process per env."""
+    import multiprocessing as mp
     out = {"numpy": np.array(np.__version__)}
-    for key, name in ENVS.items():
-        env = utils.make(name)
-        A = env.action_dim
-        n = STATS_EPISODES[key]
-        np.random.seed(20250 + ord(key[0]))                         # the reference's own generator, its own call order
-        arng = np.random.Generator(np.random.PCG64(7 + ord(key[1])))  # action_space.sample(): gymnasium draws from its own stream
-        length = np.zeros(n, np.int32); ret = np.zeros(n); viol = np.zeros(n, np.int32); crit = np.zeros(n, np.int32)
-        cbits = np.zeros((n, 3), np.int32); cause = np.zeros(n, np.uint8)
-        for e in range(n):
-            env.reset()
-            R, T, ncrit = 0.0, 0, 0
-            while True:
-                a = arng.uniform(-1.0, 1.0, A).astype(f32)
-                bits = constraint_bits(env, env.state, a)          # the reference's own check_fn on the pre-step state
-                obs, reward, term, trunc, info = env.step(a)
-                sm = info["safety_metrics"]
-                assert sm.violation_count == 3 - sum(bits)
-                R += float(reward); T += 1; ncrit += sm.critical_violations
-                for k in range(3):
-                    cbits[e, k] += 1 - bits[k]
-                if term or trunc:
-                    break
-            length[e], ret[e], viol[e], crit[e] = T, R, info["violations"], ncrit
-            cause[e] = (1 if term else 0) | (2 if trunc else 0) | (4 if info["critical_shutdown"] else 0)
-        out.update({f"{key}_length": length, f"{key}_ret": ret, f"{key}_viol": viol, f"{key}_crit": crit, f"{key}_cbits": cbits, f"{key}_cause": cause})
-        print(key, n, "episodes: length mean %.2f median %d max %d | viol/ep %.3f crit/ep %.4f | ret mean %.2f | term %.4f trunc %.4f shutdown %.4f"
-              % (length.mean(), np.median(length), length.max(), viol.mean(), crit.mean(), ret.mean(),
-                 (cause & 1).astype(bool).mean(), (cause & 2).astype(bool).mean(), (cause & 4).astype(bool).mean()), flush=True)
+    with mp.get_context("fork").Pool(3) as pool:
+        for part in pool.map(_stats_env, list(ENVS)):
+            out.update(part)
     np.savez_compressed(os.path.join(OUT, "reference_stats.npz"), **out)
 
 

@@ -327,3 +327,27 @@ def test_workspace_from_the_expandable_segments_allocator_is_accepted():
                NIG_NO_AUTOBUILD="1")
     p = subprocess.run([sys.executable, "-c", EXPANDABLE_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-1000:], p.stderr[-3000:])
+
+
+def test_clock_stamp_gives_the_shader_clock_per_compute_unit(ni):
+    """nig_clock_stamp (include/nig.h; bench.py's rank_times.clock): two stamps around a run of launches give, for every compute
+    unit stamped both times, (s_memtime1 - s_memtime0) / (s_memrealtime1 - s_memrealtime0) x 100 MHz -- a plausible shader clock,
+    nearly the same on every compute unit (the first, per-XCD version of the stamp read 2 030-5 570 "MHz": s_memtime is not one
+    counter per chip)."""
+    import bench
+    probe = bench.ClockProbe(ni, torch, torch.device("cuda", 0))
+    env = ni.make_batched("ChemicalReactor-v0", 65536, autoreset=True)
+    env.reset()
+    ring = _ring(env, 8)
+    probe.stamp(0)
+    for _ in range(40):
+        env.rollout(250, ring)
+    probe.stamp(1)
+    torch.cuda.synchronize()
+    c = probe.read()
+    env.close()
+    assert "error" not in c, c
+    assert c["compute_units"] >= 64 and 500.0 < c["shader_clock_mhz"] < 3000.0, c
+    assert c["shader_clock_mhz_p95"] / c["shader_clock_mhz_p05"] < 1.2, c          # one clock domain: a few percent across the chip
+    assert 3.0 < c["span_ms"] < 100.0, c                                             # ~40 launches of ~0.15 ms
+    assert ni._lib.lib().nig_clock_stamp(None, None) != 0                            # NULL buffer: an error code, not a fault

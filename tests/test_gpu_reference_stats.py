@@ -1,7 +1,7 @@
 """-m gpu: the statistics of the FAST MODE the driver times -- fused rollout, in-kernel generator, auto-reset -- against
 the reference's: "safety-violation-count parity" in the mode where no recorded draw exists.
 
-tests/golden/reference_stats.npz: 6 000 / 40 000 / 40 000 episodes of performance_benchmark.py:106-133's loop (uniform
+tests/golden/reference_stats.npz: 24 000 / 160 000 / 160 000 episodes of performance_benchmark.py:106-133's loop (uniform
 float32 actions, reset on done) run by the REFERENCE with its own np.random draws (chemical_reactor.py:93-103,149,159,
 power_grid.py:98-108,136-144, robot_assembly.py:118-122).  Here nig_rollout -- the kernel form bench.py times for the
 batch: three-wave ChemicalReactor at 65 536 lanes, wide-512 PowerGrid at 262 144, three-wave RobotAssembly at 65 536 --

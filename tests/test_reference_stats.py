@@ -16,13 +16,13 @@ import refstats
 from conftest import KEYS
 
 MAX_STEPS = {"cr": 500, "pg": 1000, "ra": 1000}
-LANES = {"cr": 6144, "pg": 32768, "ra": 32768}
+LANES = {"cr": 16384, "pg": 65536, "ra": 65536}
 
 
 def test_fixture_is_the_documented_sample():
     """Shape and the headline numbers BASELINE.md section 2 quotes for the reference (CR ~40 violations and 0 critical per
     episode, mean length ~350; PG ~1.0 / ~1.0, length ~5; RA median length 1, ~0.99 critical per episode)."""
-    for key, n in (("cr", 6000), ("pg", 40000), ("ra", 40000)):
+    for key, n in (("cr", 24000), ("pg", 160000), ("ra", 160000)):
         r = refstats.load_reference(key)
         assert r["length"].shape == (n,) and r["cbits"].shape == (n, 3) and r["cause"].dtype == np.uint8
         assert (r["length"] >= 1).all() and (r["length"] <= MAX_STEPS[key]).all()
