@@ -89,9 +89,11 @@ def cpu_model():
 class Workload:
     """One env type on this rank's GPU with its action ring and output buffers resident in HBM."""
 
-    def __init__(self, ni, torch, key, B, device, rank, mode, P, ring_len, outputs, traj_layout, seed=0x5EED):
+    def __init__(self, ni, torch, key, B, device, rank, mode, P, ring_len, outputs, traj_layout, seed=0x5EED, ring_layout="rows"):
         self.ni, self.torch, self.key, self.B, self.mode, self.P = ni, torch, key, B, mode, P
         self.outputs = outputs
+        # "aos": the action ring as [R, B, A] (row-major slots: a policy's batched output; nig_rollout's ld_act == 0) -- rollout mode only
+        self.ring_aos = ring_layout == "aos" and mode == "rollout"
         env = ni.make_batched(ENVS[key], B, device=device, seed=seed, env_index0=rank * B, autoreset=True, tally=True)
         self.env = env
         self.S, self.A = env.state_dim, env.action_dim
@@ -99,6 +101,8 @@ class Workload:
         self.ring = torch.empty(ring_len, self.A, env.ld, dtype=torch.float32, device=device)
         for s in range(ring_len):
             env.fill_actions(1000 + s, self.ring[s])
+        if self.ring_aos:
+            self.ring = self.ring[:, :, :B].permute(0, 2, 1).contiguous()
         env.reset()
         self.rew = self.fl = self.traj = None
         if mode == "rollout" and outputs != "none":
@@ -123,7 +127,7 @@ class Workload:
         for j in range(n):
             for s_ in range(self.P):
                 self.env.fill_actions(5000 + j * self.P + s_, big[j, s_])
-        self.rings = [big[j] for j in range(n)]
+        self.rings = [(big[j][:, :, :self.B].permute(0, 2, 1).contiguous() if self.ring_aos else big[j]) for j in range(n)]
         return n * self.P * slot_bytes
 
     def launch(self):
@@ -820,6 +824,9 @@ def parse_args(argv=None):
                          "and the headline's 196 MB ring still lives in the 256 MB Infinity Cache -- same launch time as 64 slots, "
                          "profiles/r05/headline_ring_length.txt -- while the timed workload's violations per episode move from 3.3 % "
                          "to 0.7 % under the reference's)")
+    ap.add_argument("--ring-layout", default="rows", choices=["rows", "aos"],
+                    help="action ring as [R, A, ld] rows (default) or row-major [R, B, A] slots (nig_rollout's ld_act == 0: read natively "
+                         "by PowerGrid's wide form, transposed by the library per call for every other kernel form)")
     ap.add_argument("--outputs", default="full", choices=["full", "min", "none"],
                     help="rollout mode: full = obs trajectory + reward + flags per step; min = reward + flags; none")
     ap.add_argument("--traj", default="aos", choices=["aos", "soa"], help="observation trajectory layout: [T,B,S] or [T,S,ld]")
@@ -949,11 +956,16 @@ def main():
         Bp = BASELINE_BATCH["pg"]
         # action ring of 34 slots = 285 MB: larger than the 256 MB Infinity Cache, so every action read of this record comes
         # from HBM and all 168 B per env-step are HBM-side bytes (roofline_of; a 16-slot ring sat inside the cache)
-        w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, 34, args.outputs, args.traj)
+        # ... as ROW-MAJOR slots [R][B][A] -- the layout of a policy's batched output, nig_rollout's ld_act == 0 -- which PowerGrid's
+        # wide form reads natively: a lane's eight actions are two 16-byte loads, 2 KiB contiguous per wave, where [A][ld] rows are
+        # eight 256-byte segments 1 MB apart; same bytes, same values (tests/test_gpu_action_layout.py), 1 940-1 947 vs 1 995-2 183 us
+        # on one box (profiles/r05/pg_ring_layout_ab.txt).  The rows form is timed right behind it for the record (`rows_ring`).
+        w3 = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, 34, args.outputs, args.traj, ring_layout="aos")
         K3 = max(2, min(K, 8))
         pg_times = {}
         pw, pd = timed(torch, dist, world, comm_dev, w3, K3, 2, args.settle, stats=pg_times)
         r3 = roofline_of(w3, K3, pd)
+        r3["action_ring_layout"] = "row-major [R][B][A] slots (ld_act == 0), read natively by rollout_wide_kernel"
         ptotal, pcheck = gathered_tally(torch, dist, world, comm_dev, w3)
         L = ni._lib
         powergrid = {"workload": f"PowerGrid-v0, batch={Bp} per GPU x {world} GPU(s) = {Bp * world} lanes, fused rollout, "
@@ -965,6 +977,13 @@ def main():
                      "fast_mode_statistics": fast_mode_statistics(ni, "pg", ptotal, Bp, 0 if args.no_parity else 1, device) if rank == 0 else None}
         w3.close()
         del w3
+        w3r = Workload(ni, torch, "pg", Bp, device, rank, "rollout", P, 34, args.outputs, args.traj)          # the same record with [A][ld] rows
+        rw_, rd3 = timed(torch, dist, world, comm_dev, w3r, K3, 2, min(args.settle, 0.3))
+        rr = roofline_of(w3r, K3, rd3)
+        powergrid["rows_ring"] = {"ms_per_step": rw_ * 1e3 / K3, "launch_us": rr["launch_us"], "frac": rr["frac"],
+                                  "action_ring_layout": "[R][A][ld] rows"}
+        w3r.close()
+        del w3r
 
     # ---- secondary: RobotAssembly-v0, 262144 lanes per GPU: the third reference env (robot_assembly.py:139-188, SURVEY rows
     # a15-a19) has no BASELINE config of its own; timed at PowerGrid's batch so the line carries all three (VERDICT r04 next #6b)
@@ -1001,7 +1020,7 @@ def main():
                               args.settle, per_env_rates=False)
 
     # ---- headline: workload resident in HBM before the timed region
-    wl = Workload(ni, torch, key, B, device, rank, args.mode, P, args.ring, args.outputs, args.traj)
+    wl = Workload(ni, torch, key, B, device, rank, args.mode, P, args.ring, args.outputs, args.traj, ring_layout=args.ring_layout)
     rank_times = {}
     wall, dev_ms = timed(torch, dist, world, comm_dev, wl, K, W, args.settle, stats=rank_times)
     roof = roofline_of(wl, K, dev_ms)

@@ -303,13 +303,20 @@ class BatchedIndustrialEnv:
     def rollout(self, n_steps: int, action_ring: torch.Tensor, reward_out: Optional[torch.Tensor] = None,
                 flags_out: Optional[torch.Tensor] = None, obs_out: Optional[torch.Tensor] = None):
         """n_steps fused steps in ONE kernel launch (state stays in registers; fast mode).
-        action_ring: float32 [R, A, ld>=B]; step k reads slot k % R.
+        action_ring: float32 [R, A, ld>=B] (rows), or contiguous [R, B, A] (row-major: what a policy network's batched output
+        looks like; read natively by PowerGrid's wide form, transposed into rows by the library for every other kernel form --
+        include/nig.h nig_rollout, ld_act == 0); step k reads slot k % R.
         reward_out float32 / flags_out int32: [n_steps, >=B] (per-step rows) or [B] (overwritten).
         obs_out: float32 trajectory of returned observations, [n_steps, S, >=B] (SoA rows) or
         contiguous [n_steps, B, S] (row-major transitions, D4RL layout; fastest to write)."""
         assert action_ring.dtype == torch.float32 and action_ring.dim() == 3 and action_ring.stride(2) == 1
-        R, A, ld = action_ring.shape[0], action_ring.shape[1], action_ring.stride(1)
-        assert A == self.action_dim
+        R = action_ring.shape[0]
+        if action_ring.shape[1] == self.action_dim and action_ring.shape[2] >= self.batch:
+            A, ld = action_ring.shape[1], action_ring.stride(1)                          # rows [R, A, ld]
+        else:
+            assert action_ring.shape[1:] == (self.batch, self.action_dim) and action_ring.stride(1) == self.action_dim, \
+                "action_ring is [R, A, ld >= batch] or contiguous [R, batch, A]"
+            A, ld = self.action_dim, 0                                                   # row-major [R, B, A]
 
         def out(t, dtype):
             if t is None:

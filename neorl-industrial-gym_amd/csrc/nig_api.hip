@@ -26,6 +26,16 @@ __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
 
+// row-major action ring [R][B][A] (slot stride `aos_stride` floats) -> rows [R][A][ld]: one thread per (slot, lane)
+__global__ void __launch_bounds__(BLOCK) action_rows_kernel(const float *aos, int64_t aos_stride, float *soa, int64_t ld, int64_t B, int A)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= B) return;
+    const float *src = aos + (int64_t)blockIdx.y * aos_stride + i * A;
+    float *dst = soa + (int64_t)blockIdx.y * A * ld + i;
+    for (int k = 0; k < A; ++k) dst[(int64_t)k * ld] = src[k];
+}
+
 // nig_clock_stamp: one wave per block, many more blocks than compute units; a block stamps the slot of the compute unit it
 // runs on -- slot = XCD (HW_REG_XCC_ID) x 256 + HW_REG_HW_ID's {se_id, sh_id, cu_id} -- because s_memtime is NOT one counter per
 // chip (round 5, first attempt: per-XCD slots written by whichever block came last gave 2 030 .. 5 570 "MHz" across the XCDs of
@@ -168,6 +178,7 @@ struct nig_handle {
     char *hst_dev;
     size_t hst_bytes;
     float *mirror; uint32_t ld_mirror;    // StepArgs::mirror of the next step launch (nig_step_host*), else NULL
+    float *act_soa; size_t act_soa_floats;   // nig_rollout with a row-major action ring on a kernel form that reads rows: the [A][ld] copy (owned, lazy)
 };
 
 struct nig_plan {
@@ -484,7 +495,7 @@ int nig_create(int env, int64_t batch, int device, uint64_t seed, uint64_t env_i
     h->pol_dev = (nig_policy *)(h->ws + h->lay.bytes - POLICY_BYTES);
     h->t_dev = (uint32_t *)(h->ws + h->lay.bytes - POLICY_BYTES - 256);
     h->scratch = (double *)(h->ws + h->lay.bytes - POLICY_BYTES - 256 - align_up((int64_t)REDUCE_BLOCKS * NIG_T_ROWS * 8, 256));
-    h->has_policy = false; h->mlp_stream = nullptr; h->act32 = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0; h->mirror = nullptr; h->ld_mirror = 0;
+    h->has_policy = false; h->mlp_stream = nullptr; h->act32 = nullptr; h->pid_mem = nullptr; h->may_hold_done = true; h->hst_pinned = nullptr; h->hst_dev = nullptr; h->hst_bytes = 0; h->mirror = nullptr; h->ld_mirror = 0; h->act_soa = nullptr; h->act_soa_floats = 0;
     h->state = (float *)(h->ws + h->lay.off_state); h->ld_state = h->lay.ld;
     const nig_layout &L = h->lay;
     hipLaunchKernelGGL(init_ws_kernel, dim3(grid_for(L.ld)), dim3(BLOCK), 0, (hipStream_t)0,
@@ -510,6 +521,7 @@ int nig_destroy(nig_handle *h)
     if (h->mlp_stream) (void)hipFree(h->mlp_stream);
     if (h->pid_mem) (void)hipFree(h->pid_mem);
     if (h->act32) (void)hipFree(h->act32);
+    if (h->act_soa) (void)hipFree(h->act_soa);
     if (h->hst_dev) (void)hipFree(h->hst_dev);
     if (h->hst_pinned) (void)hipHostFree(h->hst_pinned);
     if (h->owns_ws && h->ws) (void)hipFree(h->ws);
@@ -644,9 +656,18 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
                         float *obs_out, int64_t ld_obs, int64_t obs_step_stride, void *stream)
 {
     if (!h || !action_ring || n_steps <= 0 || ring_len <= 0) return fail(NIG_ERR_INVALID, "nig_rollout: bad argument%s");
-    if (ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout: ld_act outside [batch, 2^26]%s");
-    if (slot_stride < (int64_t)SPECS[h->env].action_dim * ld_act || slot_stride > 0xffffffffLL)
+    // ld_act == 0: the ring is ROW-MAJOR, slot s = [B][A] at action_ring + s * slot_stride (what an agent's batched output looks like)
+    const bool act_aos = ld_act == 0;
+    const int A_ = SPECS[h->env].action_dim;
+    if (act_aos) {
+        if (step_noise || reset_noise) return fail(NIG_ERR_UNSUPPORTED, "nig_rollout_noise: the recorded-draw launches take [A][ld_act] action rows%s");
+        if (slot_stride < (int64_t)A_ * h->B || slot_stride > 0xffffffffLL)
+            return fail(NIG_ERR_INVALID, "nig_rollout: row-major action ring: slot_stride smaller than one [batch][A] slot (or >= 2^32)%s");
+    } else {
+    if (ld_act < h->B || ld_act > NIG_MAX_PITCH) return fail(NIG_ERR_INVALID, "nig_rollout: ld_act outside {0} U [batch, 2^26]%s");
+    if (slot_stride < (int64_t)A_ * ld_act || slot_stride > 0xffffffffLL)
         return fail(NIG_ERR_INVALID, "nig_rollout: slot_stride smaller than one [A][ld_act] slot (or >= 2^32)%s");
+    }
     if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
         return fail(NIG_ERR_INVALID, "nig_rollout: out_stride outside {0} U [batch, 2^26]%s");
     if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: n_steps*out_stride >= 2^32%s");
@@ -666,6 +687,29 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
     q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
     q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = obs_aos ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (act_aos) {
+        // NATIVE where the launch is one kernel form that reads a lane's actions as contiguous bytes: PowerGrid's wide form
+        // (csrc/nig_pg_lds.hpp: two 16-byte loads per lane, 2 KiB contiguous per wave instead of eight 256-byte row segments) --
+        // i.e. an auto-reset handle without held lanes whose batch is whole 512-lane blocks, at least NIG_TUNE_WIDE_MIN_BLOCKS of
+        // them (launch_rollout_form's rule for "everything in rollout_wide_kernel<.., 512>"), 16-byte aligned slots.  Every other
+        // launch reads [A][ld] rows: the ring is transposed into a buffer the handle owns, on the caller's stream, per call.
+        const bool native = h->env == NIG_ENV_POWER_GRID && (h->flags & NIG_F_AUTORESET) != 0 && !h->may_hold_done && h->B % 512 == 0 &&
+                            q.s.wide_min_blocks < (1u << 30) && (uint64_t)(h->B / 512) >= q.s.wide_min_blocks &&
+                            ((uintptr_t)action_ring & 15) == 0 && (slot_stride & 3) == 0;
+        if (!native) {
+            const size_t need = (size_t)ring_len * A_ * (size_t)h->lay.ld;
+            if (h->act_soa_floats < need) {
+                if (h->act_soa) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(h->act_soa); h->act_soa = nullptr; h->act_soa_floats = 0; }
+                HIP_TRY(hipMalloc((void **)&h->act_soa, need * sizeof(float)));
+                h->act_soa_floats = need;
+            }
+            hipLaunchKernelGGL(nig::action_rows_kernel, dim3(grid_for(h->B), (unsigned)ring_len), dim3(BLOCK), 0, st, action_ring, slot_stride,
+                               h->act_soa, h->lay.ld, h->B, A_);
+            HIP_TRY(hipGetLastError());
+            q.s.actions = h->act_soa; q.s.ld_act = (uint32_t)h->lay.ld; q.slot_stride = (uint32_t)((int64_t)A_ * h->lay.ld);
+            if ((int64_t)A_ * h->lay.ld > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: row-major action ring: batch too large for the row copy%s");
+        }
+    }
     if ((reward_out == nullptr) != (flags_out == nullptr))
         return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
     if (obs_out && !reward_out)

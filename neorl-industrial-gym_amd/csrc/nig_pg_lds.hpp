@@ -210,7 +210,22 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
     LaneTally lt;
     lt.clear();
 
-    [[maybe_unused]] const float *ring = p.actions + base;
+    // the action ring: slot s at p.actions + s * q.slot_stride, each slot [A][ld_act] (one 256-byte row segment per action and
+    // wave) -- or, with ld_act == 0 (round 5: the layout agents produce, nig_rollout's row-major form), [B][A]: a lane's eight
+    // actions are 32 contiguous bytes, two 16-byte loads, 2 KiB contiguous per wave.  Wave-uniform switch, same values.
+    const bool act_aos = p.ld_act == 0u;
+    [[maybe_unused]] const float *ring = p.actions + (act_aos ? (size_t)base * A : (size_t)base);
+    [[maybe_unused]] auto load_action = [&](const float *slotp, float (&dst)[A]) __attribute__((always_inline)) {
+        if (act_aos) {
+            const v4f *ap = reinterpret_cast<const v4f *>(slotp) + 2u * tid;
+            const v4f w0 = ap[0], w1 = ap[1];
+            dst[0] = w0.x; dst[1] = w0.y; dst[2] = w0.z; dst[3] = w0.w; dst[4] = w1.x; dst[5] = w1.y; dst[6] = w1.z; dst[7] = w1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) dst[k] = (slotp + k * p.ld_act)[tid];
+        }
+    };
+    static_assert(A == 8, "row-major action slots are read as two float4 per lane");
     // ONE action register set: the action of step it + 1 is loaded into it as soon as step it has consumed its own
     // (clip, generation update, the reward's action term: the first ~80 instructions of a step), i.e. a whole step
     // (~1 200 instructions, four waves sharing the SIMD) before it is used.  The wait for it is in order with the stores
@@ -366,8 +381,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
             slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
             act_next = (slot == 0) ? ring : act_next + q.slot_stride;
 #else
-#pragma unroll
-            for (int k = 0; k < A; ++k) abuf[k] = (act_next + k * p.ld_act)[tid];
+            load_action(act_next, abuf);
             slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
             act_next = (slot == 0) ? ring : act_next + q.slot_stride;
 #endif
@@ -593,9 +607,7 @@ __device__ __forceinline__ void pg_lds_rollout_body(const QA &q, const uint32_t 
     if constexpr (!POLICY) {
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
-        const float *nx = ring + (size_t)slot * q.slot_stride;
-#pragma unroll
-        for (int k = 0; k < A; ++k) buf[j][k] = (nx + k * p.ld_act)[tid];
+        load_action(ring + (size_t)slot * q.slot_stride, buf[j]);
         slot = (slot + 1 == q.ring_len) ? 0 : slot + 1;
     }
     act_next = ring + (size_t)slot * q.slot_stride;

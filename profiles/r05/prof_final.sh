@@ -73,6 +73,27 @@ PY
   done
   cat $R/mlp_cr65536_head4_sq.txt; head -12 $R/pg262144_rollout_full_sq.txt; head -12 $R/pg262144_rollout_full_lds_sq.txt
 fi
+if [ $part = E ]; then
+  # PowerGrid with the row-major action ring (the driver line's PowerGrid record since the end of round 5): kernel stats, traffic, SQ
+  run python3 bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/r05_driver_final3.err | grep '^{' > $R/driver_bench_final3.json
+  NIG_PROFILE_EXTRA="--no-step-api --no-brackets --no-single-env" run bash profiles/run_profile.sh r05_pg262144_aos_full --env pg --ring 34 --ring-layout aos --steps 300 --warmup 5 > gpurun_out/r05_prof_pg_aos.log 2>&1 \
+    && cp gpurun_out/prof_r05_pg262144_aos_full/r05_pg262144_aos_full_kernel_stats.csv $R/pg262144_rowmajor_ring_full_kernel_stats.csv && cp gpurun_out/prof_r05_pg262144_aos_full/bench.json $R/pg262144_rowmajor_ring_full_bench.json
+  NIG_PROFILE_EXTRA="--no-step-api --no-brackets --no-single-env" run bash profiles/run_profile.sh r05_pg262144_rows_full --env pg --ring 34 --steps 300 --warmup 5 > gpurun_out/r05_prof_pg_rows.log 2>&1 \
+    && cp gpurun_out/prof_r05_pg262144_rows_full/r05_pg262144_rows_full_kernel_stats.csv $R/pg262144_rows_ring_full_kernel_stats_box3.csv
+  run bash profiles/run_pmc.sh r05_pg262144_rollout_full --env pg --ring 34 --ring-layout aos --steps 10 --warmup 2 > gpurun_out/r05_pmc_pg_aos.log 2>&1 \
+    && cp gpurun_out/pmc_r05_pg262144_rollout_full/traffic_r05_pg262144_rollout_full.json $R/r05_pg262144_rowmajor_ring_pmc_traffic.json
+  cp profiles/traffic.json $R/traffic_merged.json
+  run bash profiles/run_sq.sh r05_pg262144_aos_issue --env pg --ring 34 --ring-layout aos --steps 8 --warmup 2 > $R/pg262144_rowmajor_ring_full_sq.txt 2> gpurun_out/r05_sq_pg_aos.err
+  head -3 $R/pg262144_rowmajor_ring_full_kernel_stats.csv; head -2 $R/pg262144_rows_ring_full_kernel_stats_box3.csv | tail -1; tail -4 gpurun_out/r05_pmc_pg_aos.log; head -10 $R/pg262144_rowmajor_ring_full_sq.txt
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/profiles_r05/driver_bench_final3.json"))
+r = d["roofline"]; pg = d["powergrid"]
+print("headline %.4g, %.1f us, frac %.3f | pg %.3f ms frac %.3f (rows ring %.3f ms frac %.3f) | ra %.3f ms %.3f | mixed %.3f ms %.3f" % (
+    d["value"], r["launch_us"], r["frac"], pg["ms_per_step"], pg["roofline"]["frac"], pg["rows_ring"]["ms_per_step"], pg["rows_ring"]["frac"],
+    d["robotassembly"]["ms_per_step"], d["robotassembly"]["roofline"]["frac"], d["mixed"]["ms_per_step"], d["mixed"]["roofline"]["frac"]))
+PY
+fi
 if [ $part = D ]; then
   timeout -k 10 1100 bash profiles/sweep.sh r05 > gpurun_out/r05_sweep.log 2>&1
   cp gpurun_out/sweep_r05.jsonl $R/sweep_r05.jsonl; tail -45 gpurun_out/r05_sweep.log > $R/sweep_r05.txt; cat $R/sweep_r05.txt
