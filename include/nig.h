@@ -424,7 +424,9 @@ int nig_rollout_policy(nig_handle *h, int32_t n_steps, float *reward_out, uint32
  * hidden activations never leave the accumulator registers (an accumulator tile is the next
  * layer's B operand as it stands).  Weights are host pointers, row-major [in][out] (the layout of
  * a Flax Dense kernel); the library re-orders them once into the MFMA operand stream and keeps
- * that copy in device memory it owns.  hidden must be 256.
+ * that copy in device memory it owns.  hidden must be 256.  The tanh head runs on K = 1 MFMAs sized
+ * to the env's action count (v_mfma_f32_4x4x1 up to four actions, v_mfma_f32_16x16x1 up to sixteen);
+ * envs with an odd state dim or more than sixteen actions are refused (NIG_ERR_UNSUPPORTED).
  */
 int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *W3, const float *b3, void *stream);

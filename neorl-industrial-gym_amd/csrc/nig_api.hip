@@ -822,7 +822,7 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
     if (!h || !W1 || !b1 || !W2 || !b2 || !W3 || !b3) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: NULL argument%s");
     if (hidden != MLP_H) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: hidden must be 256 (agents/networks.py default)%s");
     const int S = SPECS[h->env].state_dim, A = SPECS[h->env].action_dim, H = MLP_H;
-    if (S % 2 != 0 || A > 8) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: env shape not supported%s");
+    if (S % 2 != 0 || A > 16) return fail(NIG_ERR_UNSUPPORTED, "nig_set_mlp_policy: env shape not supported (even state dim, at most 16 actions)%s");
     float *host = (float *)calloc((size_t)MLP_STREAM_FLOATS, sizeof(float));
     if (!host) return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: out of host memory%s");
     // Build the operand stream in exactly the order rollout_mlp_kernel consumes it, chunk by chunk (a chunk = one
@@ -847,7 +847,8 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
             for (int l = 0; l < 64; ++l) {
                 if (A <= 4) {                                 // v_mfma_f32_4x4x1: lane 4 b + i of every 4-lane block holds head row i of ITS half's hidden row
                     if ((l & 3) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 3)];
-                } else if ((l & 31) < A) rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 31)];
+                } else if ((l & 15) < A)                      // v_mfma_f32_16x16x1 (four blocks): lane 16 b + i holds head row i of block b's hidden row
+                    rec(1 + m2, r)[l] = W3[(size_t)(32 * m2 + mfma_row(t, l >> 5)) * A + (l & 15)];
             }
         if (r != MLP_PER) { free(host); return fail(NIG_ERR_INVALID, "nig_set_mlp_policy: internal record count mismatch%s"); }
     }
@@ -855,7 +856,8 @@ int nig_set_mlp_policy(nig_handle *h, int32_t hidden, const float *W1, const flo
         for (int l = 0; l < 64; ++l)
             if ((l & 3) < A) rec(MLP_MT, MLP_PER)[l] = b3[l & 3];    // (4 x 4 x 1: every block's row lanes; B = 1 on lane half 0, 0 on half 1)
     } else
-        for (int l = 0; l < A; ++l) rec(MLP_MT, MLP_PER)[l] = b3[l];
+        for (int l = 0; l < 64; ++l)
+            if ((l & 15) < A) rec(MLP_MT, MLP_PER)[l] = b3[l & 15];
     hipError_t e = hipSuccess;
     if (!h->mlp_stream) e = hipMalloc((void **)&h->mlp_stream, (size_t)MLP_STREAM_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(h->mlp_stream, host, (size_t)MLP_STREAM_FLOATS * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -870,7 +872,7 @@ int nig_rollout_mlp(nig_handle *h, int32_t n_steps, float *reward_out, uint32_t 
                     void *stream)
 {
     if (!h || n_steps <= 0) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: bad argument%s");
-    if (!h->mlp_stream) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: no actor installed (nig_set_mlp_policy)%s");
+    if (!h->mlp_stream || !launch_of(h->env)->mlp) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: no actor installed (nig_set_mlp_policy)%s");
     if (out_stride != 0 && (out_stride < h->B || out_stride > NIG_MAX_PITCH))
         return fail(NIG_ERR_INVALID, "nig_rollout_mlp: out_stride outside {0} U [batch, 2^26]%s");
     if ((int64_t)n_steps * out_stride > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout_mlp: n_steps*out_stride >= 2^32%s");

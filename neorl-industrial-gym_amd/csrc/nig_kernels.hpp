@@ -1646,7 +1646,13 @@ typedef __attribute__((address_space(1))) const void nig_glb_void;
 // instruction, where the 32 x 32 x 2 tile spent 64 cycles on 32 rows of which 29 were zero padding (11 % of the step's MFMA
 // time).  Each lane half accumulates the hidden rows ITS accumulator registers hold (rho_h(t)), the two
 // partial sums meet in one v_add_f32 across the halves: a different summation order from the 32 x 32 x 2 head (k0, k1
-// interleaved), restated by the oracle (mlp_actor, A <= 4).
+// interleaved), restated by the oracle (mlp_actor).
+// Heads of FIVE TO SIXTEEN actions take the same route on v_mfma_f32_16x16x1_4B_f32: four 16 x 16 blocks of sixteen lanes, K = 1,
+// 32 cycles.  Block b = lane >> 4 multiplies its lanes' own h2 values (B: hidden row rho_{b>>1}(t), envs 16 (b & 1) ..) with the
+// sixteen head weights its lanes hold (A: lane 16 b + r holds W3[k_b][r]) into registers 4 b .. 4 b + 3 (row r of env column c in
+// register 4 b + (r & 3) of lane 16 (r >> 2) + c): blocks 0 / 1 are lane half 0's fma chain for envs 0-15 / 16-31, blocks 2 / 3
+// lane half 1's -- the SAME two chains and the same joining add as the 4 x 4 x 1 head, so the oracle has one head for every env.
+// The 32 x 32 x 2 head (64 cycles for 32 rows, 24 of them padding with eight actions) is gone.
 template <class Env> constexpr bool mlp_head4 = Env::A <= 4;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -1657,7 +1663,7 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
 {
     constexpr int S = Env::S, A = Env::A, KS = Env::KS, KR = Env::KR;
     constexpr int KSN = KS > 0 ? KS : 1;
-    static_assert(S % 2 == 0 && A <= 8, "MFMA actor needs an even state dim and at most 8 actions");
+    static_assert(S % 2 == 0 && A <= 16, "MFMA actor needs an even state dim and at most 16 actions");
     // Weight records are shared by the four waves of the block through LDS: round 1 let every wave stream all
     // ~1 200 records of a step from L2 on its own (the same 256-byte lines requested by every wave of the chip at
     // about the same time: 96 TFLOP/s of 155).  Now the block fills a double-buffered LDS image chunk by chunk with
@@ -1749,14 +1755,14 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, half ? 0.0f : 1.0f, acc, 0, 0, 0);      // + b2
                 } else if constexpr (mlp_head4<Env>) {  // this h2 tile is consumed at once by the head: 4 x 4 x 1, own value x the block's weights
                     out4 = __builtin_amdgcn_mfma_f32_4x4x1f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out4, 0, 0, 0);
-                } else {
-                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out, 0, 0, 0);
+                } else {                                // 16 x 16 x 1, four blocks: own value x the block's sixteen weights
+                    out = __builtin_amdgcn_mfma_f32_16x16x1f32(aop, fmaxf(acc[i - MLP_MT * 16 - 1], 0.0f), out, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (m2 + 1 == MLP_MT) {                          // record 145 of the last chunk: + b3
                 if constexpr (mlp_head4<Env>) out4 = __builtin_amdgcn_mfma_f32_4x4x1f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out4, 0, 0, 0);
-                else out = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out, 0, 0, 0);
+                else out = __builtin_amdgcn_mfma_f32_16x16x1f32(ring[MLP_PER % RING], half ? 0.0f : 1.0f, out, 0, 0, 0);
             }
             gbuf ^= 1;
         }
@@ -1765,14 +1771,16 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
 #pragma unroll
             for (int r = 0; r < A; ++r) a[r] = det_tanhf(out4[r] + __shfl_xor(out4[r], 32));
         } else {
-        // action j sits in register j&3 of lane half j>>2: hand every lane all A of them
+            // head row r of env column c (env 16 beta + c, beta = block parity): lane 16 (r >> 2) + c, registers 4 beta + (r & 3)
+            // (lane half 0's chain) and 8 + 4 beta + (r & 3) (lane half 1's); hand every lane all A rows of its env
+            const int beta = (int)(e >> 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mine = out[r];
-            const float other = __shfl_xor(mine, 32);
-            if (r < A) a[r] = det_tanhf(half ? other : mine);
-            if (r + 4 < A) a[r + 4] = det_tanhf(half ? mine : other);
-        }
+            for (int r = 0; r < A; ++r) {
+                const int src = 16 * (r >> 2) + (int)(e & 15u);
+                const float v0 = __shfl(out[r & 3] + out[8 + (r & 3)], src);
+                const float v1 = __shfl(out[4 + (r & 3)] + out[12 + (r & 3)], src);
+                a[r] = det_tanhf(beta ? v1 : v0);
+            }
         }
 
         // ---------------- IndustrialEnv.step (both lane halves, identical results) ----------------
@@ -1921,11 +1929,11 @@ static void launch_reset(const ResetArgs &a, bool parity, unsigned grid, hipStre
     else hipLaunchKernelGGL((reset_kernel<Env, false>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-// the MFMA actor exists for even state dims and at most 8 actions (nig_set_mlp_policy refuses the others)
+// the MFMA actor exists for even state dims and at most 16 actions (nig_set_mlp_policy refuses the others)
 template <class Env>
 static void launch_mlp(const MlpArgs &q, unsigned grid, hipStream_t st)
 {
-    if constexpr (Env::S % 2 == 0 && Env::A <= 8) hipLaunchKernelGGL((rollout_mlp_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, q);
+    if constexpr (Env::S % 2 == 0 && Env::A <= 16) hipLaunchKernelGGL((rollout_mlp_kernel<Env>), dim3(grid), dim3(BLOCK), 0, st, q);
 }
 
 template <class Env>
@@ -2159,7 +2167,7 @@ template <class Env>
 static const EnvLaunch *env_launch_table()
 {
     static const EnvLaunch T = {launch_step<Env>, Env::HAS_ACT64 ? launch_step64<Env> : nullptr, launch_rollout_env<Env>, launch_policy<Env>,
-                                (Env::S % 2 == 0 && Env::A <= 8) ? launch_mlp<Env> : nullptr,
+                                (Env::S % 2 == 0 && Env::A <= 16) ? launch_mlp<Env> : nullptr,
                                 launch_reset<Env>, launch_fill<Env>};
     return &T;
 }

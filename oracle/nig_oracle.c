@@ -1492,30 +1492,19 @@ static void mlp_actor(int S, int A, const float *W1, const float *b1, const floa
         h2[v] = fmaxf(acc, 0.0f);
     }
     for (int j = 0; j < A; j++) {
-        if (A <= 4) {
-            /* heads of at most four rows run on v_mfma_f32_4x4x1 on the device (nig_kernels.hpp mlp_head4): each lane half sums
-             * the hidden rows its accumulator registers hold -- half 0 rows rho(t), half 1 rows rho(t) + 4 -- as its own fma
-             * chain, the bias record is fma(b, 1, .) on half 0 and fma(b, 0, .) on half 1, one float32 add joins the halves */
-            float acc0 = 0.0f, acc1 = 0.0f;
-            for (int kt = 0; kt < MLP_H / 32; kt++)
-                for (int t = 0; t < 16; t++) {
-                    int k0 = 32 * kt + mlp_rho(t), k1 = k0 + 4;
-                    acc0 = fmaf(W3[(size_t)k0 * A + j], h2[k0], acc0);
-                    acc1 = fmaf(W3[(size_t)k1 * A + j], h2[k1], acc1);
-                }
-            acc0 = fmaf(b3[j], 1.0f, acc0); acc1 = fmaf(b3[j], 0.0f, acc1);
-            act[j] = det_tanhf(acc0 + acc1);
-            continue;
-        }
-        float acc = 0.0f;
+        /* the head runs on K = 1 MFMAs on the device (nig_kernels.hpp: v_mfma_f32_4x4x1 for at most four actions,
+         * v_mfma_f32_16x16x1 above): each lane half sums the hidden rows its accumulator registers hold -- half 0 rows
+         * rho(t), half 1 rows rho(t) + 4 -- as its own fma chain, the bias record is fma(b, 1, .) on half 0 and
+         * fma(b, 0, .) on half 1, one float32 add joins the halves */
+        float acc0 = 0.0f, acc1 = 0.0f;
         for (int kt = 0; kt < MLP_H / 32; kt++)
             for (int t = 0; t < 16; t++) {
                 int k0 = 32 * kt + mlp_rho(t), k1 = k0 + 4;
-                acc = fmaf(W3[(size_t)k0 * A + j], h2[k0], acc);
-                acc = fmaf(W3[(size_t)k1 * A + j], h2[k1], acc);
+                acc0 = fmaf(W3[(size_t)k0 * A + j], h2[k0], acc0);
+                acc1 = fmaf(W3[(size_t)k1 * A + j], h2[k1], acc1);
             }
-        acc = fmaf(b3[j], 1.0f, acc); acc = fmaf(0.0f, 0.0f, acc);
-        act[j] = det_tanhf(acc);
+        acc0 = fmaf(b3[j], 1.0f, acc0); acc1 = fmaf(b3[j], 0.0f, acc1);
+        act[j] = det_tanhf(acc0 + acc1);
     }
 }
 

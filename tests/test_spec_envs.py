@@ -247,7 +247,7 @@ def test_single_env_surface(ni, oracle, key):
             obs, info = env.reset()
     assert seen > 0
     env.close()
-    if A > 8 or S % 2:                                  # the MFMA actor exists for <= 8 actions and even state dims
+    if A > 16 or S % 2:                                 # the MFMA actor exists for <= 16 actions and even state dims
         b = ni.make_batched(name, 64)
         z = np.zeros
         with pytest.raises(ni._lib.NigError):
