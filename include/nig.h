@@ -315,9 +315,10 @@ int nig_plan_destroy(nig_plan *p);
  *                output (agents/base.py:106-141 predict() returns [n, A]).  Read natively (two 16-byte loads per lane, 2 KiB
  *                contiguous per wave) where the whole launch is PowerGrid's wide form (auto-reset handle, no held lanes,
  *                batch a multiple of 512 and at least NIG_TUNE_WIDE_MIN_BLOCKS such blocks, 16-byte aligned slots); every
- *                other launch reads rows, so the library first transposes the ring into a buffer the handle owns
- *                (ring_len*A*ld floats, allocated on first use, on the caller's stream, EVERY call: prefer rows for a ring
- *                that is replayed).  Same values either way (tests/test_gpu_action_layout.py).
+ *                other launch reads rows, so the library first transposes the slots this call reads (the first
+ *                min(ring_len, n_steps): step k takes slot k % ring_len) into a buffer the handle owns (that many times
+ *                A*ld floats, grown on demand, on the caller's stream, EVERY call: prefer rows for a ring that is
+ *                replayed).  Same values either way (tests/test_gpu_action_layout.py).
  *   reward_out, flags_out   optional (both or neither), row of step k at base + k*out_stride
  *                (0 = overwrite)
  *   obs_out      optional (needs reward_out/flags_out) float trajectory: observation returned by step k (the terminal one for

@@ -26,14 +26,17 @@ __global__ void __launch_bounds__(BLOCK) init_ws_kernel(uint32_t *ctr, long long
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
 
-// row-major action ring [R][B][A] (slot stride `aos_stride` floats) -> rows [R][A][ld]: one thread per (slot, lane)
-__global__ void __launch_bounds__(BLOCK) action_rows_kernel(const float *aos, int64_t aos_stride, float *soa, int64_t ld, int64_t B, int A)
+// row-major action ring [R][B][A] (slot stride `aos_stride` floats) -> rows [R][A][ld]: one thread per lane, slots blockIdx.y,
+// blockIdx.y + gridDim.y, ... (the grid's y extent is capped at 65 535)
+__global__ void __launch_bounds__(BLOCK) action_rows_kernel(const float *aos, int64_t aos_stride, float *soa, int64_t ld, int64_t B, int A, int slots)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
-    const float *src = aos + (int64_t)blockIdx.y * aos_stride + i * A;
-    float *dst = soa + (int64_t)blockIdx.y * A * ld + i;
-    for (int k = 0; k < A; ++k) dst[(int64_t)k * ld] = src[k];
+    for (int r = (int)blockIdx.y; r < slots; r += (int)gridDim.y) {
+        const float *src = aos + (int64_t)r * aos_stride + i * A;
+        float *dst = soa + (int64_t)r * A * ld + i;
+        for (int k = 0; k < A; ++k) dst[(int64_t)k * ld] = src[k];
+    }
 }
 
 // nig_clock_stamp: one wave per block, many more blocks than compute units; a block stamps the slot of the compute unit it
@@ -687,6 +690,10 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
     q.n_steps = n_steps; q.it0 = 0; q.ring_len = ring_len; q.slot_stride = (uint32_t)slot_stride; q.out_stride = (uint32_t)out_stride;
     q.obs_out = obs_out; q.ld_obs_out = (uint32_t)ld_obs; q.obs_step_stride = (uint64_t)obs_step_stride; q.obs_aos = obs_aos ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    if ((reward_out == nullptr) != (flags_out == nullptr))
+        return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
+    if (obs_out && !reward_out)
+        return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
     if (act_aos) {
         // NATIVE where the launch is one kernel form that reads a lane's actions as contiguous bytes: PowerGrid's wide form
         // (csrc/nig_pg_lds.hpp: two 16-byte loads per lane, 2 KiB contiguous per wave instead of eight 256-byte row segments) --
@@ -697,23 +704,20 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
                             q.s.wide_min_blocks < (1u << 30) && (uint64_t)(h->B / 512) >= q.s.wide_min_blocks &&
                             ((uintptr_t)action_ring & 15) == 0 && (slot_stride & 3) == 0;
         if (!native) {
-            const size_t need = (size_t)ring_len * A_ * (size_t)h->lay.ld;
+            if ((int64_t)A_ * h->lay.ld > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: row-major action ring: batch too large for the row copy%s");
+            const int used = ring_len < n_steps ? ring_len : n_steps;     // the slots this call reads: step k takes slot k % ring_len, from 0
+            const size_t need = (size_t)used * A_ * (size_t)h->lay.ld;
             if (h->act_soa_floats < need) {
                 if (h->act_soa) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(h->act_soa); h->act_soa = nullptr; h->act_soa_floats = 0; }
                 HIP_TRY(hipMalloc((void **)&h->act_soa, need * sizeof(float)));
                 h->act_soa_floats = need;
             }
-            hipLaunchKernelGGL(nig::action_rows_kernel, dim3(grid_for(h->B), (unsigned)ring_len), dim3(BLOCK), 0, st, action_ring, slot_stride,
-                               h->act_soa, h->lay.ld, h->B, A_);
+            hipLaunchKernelGGL(nig::action_rows_kernel, dim3(grid_for(h->B), (unsigned)(used < 65535 ? used : 65535)), dim3(BLOCK), 0, st,
+                               action_ring, slot_stride, h->act_soa, h->lay.ld, h->B, A_, used);
             HIP_TRY(hipGetLastError());
             q.s.actions = h->act_soa; q.s.ld_act = (uint32_t)h->lay.ld; q.slot_stride = (uint32_t)((int64_t)A_ * h->lay.ld);
-            if ((int64_t)A_ * h->lay.ld > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: row-major action ring: batch too large for the row copy%s");
         }
     }
-    if ((reward_out == nullptr) != (flags_out == nullptr))
-        return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
-    if (obs_out && !reward_out)
-        return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
     const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
     if (step_noise || reset_noise) {               // nig_rollout_noise: the reference's recorded draws
         const nig_env_spec &sp = SPECS[h->env];

@@ -45,7 +45,7 @@ def _run(ni, key, B, layout, chunks, outputs, R, seed=31, max_steps=17):
     used = free0 - torch.cuda.mem_get_info()[0]
     got += [env.state_soa.cpu(), env.ctr.cpu(), env.life_viol.cpu(), env.ep_return.cpu(), env.tally.cpu()]
     env.close()
-    return got, used, R * env.action_dim * env.ld * 4
+    return got, used, min(R, max(chunks)) * env.action_dim * env.ld * 4        # bytes of the slots one call reads
 
 
 def _same(a, b):
@@ -61,7 +61,7 @@ def test_powergrid_wide_form_reads_a_row_major_ring_natively(ni, outputs):
     """Whole 512-lane blocks in the wide form (knob at one block): chained launches with ring wrap, truncations, terminations and
     in-kernel resets; row-major ring == rows, and no ring-sized allocation appears on the device."""
     ni.tune(wide_min_blocks=1, split_blocks=0)
-    kw = dict(key="pg", B=4096, chunks=[23, 9], outputs=outputs, R=512)          # 512 slots x 8 x 4096 x 4 B = 64 MiB ring
+    kw = dict(key="pg", B=4096, chunks=[200, 9], outputs=outputs, R=512)         # 512 slots x 8 x 4096 x 4 B = 64 MiB ring, 200 of them read
     a, used_a, ring_bytes = _run(ni, layout="rows", **kw)
     b, used_b, _ = _run(ni, layout="aos", **kw)
     _same(a, b)
@@ -73,9 +73,10 @@ def test_powergrid_wide_form_reads_a_row_major_ring_natively(ni, outputs):
 def test_other_forms_take_a_row_major_ring_through_the_row_copy(ni, key, B):
     """A ragged PowerGrid batch (wide + 256-lane + one-wave launches), a PowerGrid batch below the wide threshold, ChemicalReactor
     and RobotAssembly in their three-wave and one-wave forms: the library transposes the ring into rows it owns (a ring-sized
-    allocation appears), results equal the rows' bit for bit; a second call reuses the buffer."""
+    allocation appears: the slots a call reads, min(ring_len, n_steps) of them), results equal the rows' bit for bit; a second
+    call reuses the buffer."""
     ni.tune(wide_min_blocks=-1, split_blocks=-1)
-    kw = dict(key=key, B=B, chunks=[19, 6], outputs="aos", R=64)
+    kw = dict(key=key, B=B, chunks=[70, 6], outputs="aos", R=64)               # (70 steps: the ring wraps inside the call)
     a, _, ring_bytes = _run(ni, layout="rows", **kw)
     b, used_b, _ = _run(ni, layout="aos", **kw)
     _same(a, b)
