@@ -367,6 +367,27 @@ def honest_brackets(torch, wl, K, roof, settle_s, idle_gap=1.0, phases=None):
     out["ring_gt_mall"] = {"ring_bytes": ring_bytes, "rings": len(wl.rings), "launch_us": us,
                            "frac": frac_of(hbm_side_bytes(wl)[0], us),       # every byte from HBM: == the algorithmic figure
                            "frac_algorithmic": frac_of(roof["alg_bytes_per_env_step"], us)}
+    out["stream_probe"] = stream_probe(torch, wl.env.device)
+    return out
+
+
+def stream_probe(torch, device, nbytes=2 * 2**30, reps=8):
+    """Context for `frac` (peak = the guide's 8 TB/s): what plain streaming kernels reach on THIS box at THIS moment over buffers
+    eight times the Infinity Cache -- torch's fill (write only: the shape of the headline's trajectory stores) and a
+    device-to-device copy (read + write, both directions counted).  Library kernels on torch's stream, torch events."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    out = {"bytes": nbytes, "reps": reps}
+    for name, op, moved in (("fill_GBps", lambda: a.fill_(1.0), nbytes), ("copy_GBps", lambda: b.copy_(a), 2 * nbytes)):
+        op(); op()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            op()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
     return out
 
 
