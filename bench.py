@@ -720,14 +720,26 @@ def scale_record(world, rehearse, affinity, dist=None):
     return rec
 
 
-def measure_single_env(ni, n_steps=1000, warm=100):
+def measure_single_env(ni, n_steps=1000, warm=100, settle_s=0.25):
     """BASELINE configs[0] as written: ChemicalReactor-v0, batch = 1 env, a 1000-step rollout with reset on done -- the
     reference's own harness loop (performance_benchmark.py:106-133) on the single-env drop-in class (ni.make): one
     step-kernel launch + one host round trip per env.step through pinned staging.  Launch / PCIe latency bound by
-    construction; it is the plumbing configuration, timed so the line carries every BASELINE config."""
+    construction; it is the plumbing configuration, timed so the line carries every BASELINE config.
+    Settle: like the fused records (`--settle`), the loop first runs untimed -- `settle_s` seconds of steps.  A fresh process
+    on an idle GPU takes ~115 us per launch + round trip for its first ~50 ms and ~23 us from then on
+    (profiles/r05/single_env_warmup.txt); 100 warm-up steps end inside that ramp, which is what made this record read
+    16-18 k steps/s on some boxes and 45 k on others for the same build."""
     import numpy as np
     env = ni.make("ChemicalReactor-v0")
     rng = np.random.default_rng(0)
+    env.reset()
+    settled, t_s = 0, time.perf_counter()
+    zero = np.zeros(3, dtype=np.float32)
+    while time.perf_counter() - t_s < settle_s:
+        _, _, te, tr, _ = env.step(zero)
+        settled += 1
+        if te or tr:
+            env.reset()
     acts = rng.uniform(-1.0, 1.0, size=(n_steps + warm, 3)).astype(np.float32)    # action_space.sample()-equivalent
     env.reset()
     viol = eps = 0
@@ -746,7 +758,7 @@ def measure_single_env(ni, n_steps=1000, warm=100):
     return {"workload": f"ChemicalReactor-v0, batch=1 env, {n_steps}-step rollout, reset on done (BASELINE configs[0]; "
                         "single-env drop-in class, host buffers, one launch per env.step)",
             "value": n_steps / dt, "unit": "env-steps/s", "us_per_step": dt / n_steps * 1e6, "steps": n_steps,
-            "episodes": eps, "violations": viol,
+            "episodes": eps, "violations": viol, "settle_steps": settled, "warmup_steps": warm,
             "reference_python_1core": REFERENCE_PYTHON_1CORE,
             "note": "PCIe/launch-latency bound (includes the host round trip of every step; never the headline `value`)"}
 
