@@ -313,8 +313,9 @@ int nig_plan_destroy(nig_plan *p);
  *   action_ring / ld_act / slot_stride / ring_len   as for nig_plan_create; or, with ld_act == 0, a ROW-MAJOR ring: slot s =
  *                [batch][A] at action_ring + s*slot_stride (slot_stride >= batch*A) -- the layout of a policy's batched
  *                output (agents/base.py:106-141 predict() returns [n, A]).  Read natively (two 16-byte loads per lane, 2 KiB
- *                contiguous per wave) where the whole launch is PowerGrid's wide form (auto-reset handle, no held lanes,
- *                batch a multiple of 512 and at least NIG_TUNE_WIDE_MIN_BLOCKS such blocks, 16-byte aligned slots); every
+ *                contiguous per wave) where every kernel of the launch is PowerGrid's LDS-resident body (auto-reset handle,
+ *                no held lanes, batch a multiple of 256, 16-byte aligned slots; not the small-batch launches without an
+ *                observation trajectory, whose stepping waves keep the state in registers); every
  *                other launch reads rows, so the library first transposes the slots this call reads (the first
  *                min(ring_len, n_steps): step k takes slot k % ring_len) into a buffer the handle owns (that many times
  *                A*ld floats, grown on demand, on the caller's stream, EVERY call: prefer rows for a ring that is

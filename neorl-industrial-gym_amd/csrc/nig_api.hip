@@ -694,15 +694,14 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
         return fail(NIG_ERR_INVALID, "nig_rollout: reward_out and flags_out go together (both or neither)%s");
     if (obs_out && !reward_out)
         return fail(NIG_ERR_INVALID, "nig_rollout: an observation trajectory needs reward_out and flags_out too%s");
+    const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
     if (act_aos) {
-        // NATIVE where the launch is one kernel form that reads a lane's actions as contiguous bytes: PowerGrid's wide form
-        // (csrc/nig_pg_lds.hpp: two 16-byte loads per lane, 2 KiB contiguous per wave instead of eight 256-byte row segments) --
-        // i.e. an auto-reset handle without held lanes whose batch is whole 512-lane blocks, at least NIG_TUNE_WIDE_MIN_BLOCKS of
-        // them (launch_rollout_form's rule for "everything in rollout_wide_kernel<.., 512>"), 16-byte aligned slots.  Every other
-        // launch reads [A][ld] rows: the ring is transposed into a buffer the handle owns, on the caller's stream, per call.
-        const bool native = h->env == NIG_ENV_POWER_GRID && (h->flags & NIG_F_AUTORESET) != 0 && !h->may_hold_done && h->B % 512 == 0 &&
-                            q.s.wide_min_blocks < (1u << 30) && (uint64_t)(h->B / 512) >= q.s.wide_min_blocks &&
-                            ((uintptr_t)action_ring & 15) == 0 && (slot_stride & 3) == 0;
+        // NATIVE where every kernel of the launch reads a lane's actions as contiguous bytes: PowerGrid's LDS-resident body
+        // (csrc/nig_pg_lds.hpp: two 16-byte loads per lane, 2 KiB contiguous per wave instead of eight 256-byte row segments) in its
+        // wide 512 / 256 and paired forms -- the launcher's own predicate (rollout_rows_native, next to launch_rollout_form) -- and
+        // 16-byte aligned slots.  Every other launch reads [A][ld] rows: the ring is transposed into a buffer the handle owns, on
+        // the caller's stream, per call.
+        const bool native = launch_of(h->env)->rows_native(out_mode, q) && ((uintptr_t)action_ring & 15) == 0 && (slot_stride & 3) == 0;
         if (!native) {
             if ((int64_t)A_ * h->lay.ld > 0xffffffffLL) return fail(NIG_ERR_INVALID, "nig_rollout: row-major action ring: batch too large for the row copy%s");
             const int used = ring_len < n_steps ? ring_len : n_steps;     // the slots this call reads: step k takes slot k % ring_len, from 0
@@ -718,7 +717,6 @@ static int rollout_impl(nig_handle *h, int32_t n_steps, const float *action_ring
             q.s.actions = h->act_soa; q.s.ld_act = (uint32_t)h->lay.ld; q.slot_stride = (uint32_t)((int64_t)A_ * h->lay.ld);
         }
     }
-    const int out_mode = !reward_out ? 0 : (!obs_out ? 1 : (obs_aos ? 3 : 2));
     if (step_noise || reset_noise) {               // nig_rollout_noise: the reference's recorded draws
         const nig_env_spec &sp = SPECS[h->env];
         if (h->env > NIG_ENV_ROBOT_ASSEMBLY)

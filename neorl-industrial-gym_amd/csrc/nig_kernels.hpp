@@ -1920,6 +1920,8 @@ struct EnvLaunch {
     void (*reset)(const ResetArgs &, bool parity, unsigned grid, hipStream_t);
     void (*fill)(float *act, int64_t ld_act, int64_t B, uint64_t env0, uint32_t seed_lo, uint32_t seed_hi, uint32_t t,
                  unsigned grid, hipStream_t);
+    // does `rollout` read a ROW-MAJOR action ring ([B][A] slots, RolloutArgs.s.ld_act == 0) natively for this request?
+    bool (*rows_native)(int out_mode, const RolloutArgs &);
 };
 
 template <class Env>
@@ -2086,6 +2088,29 @@ static void launch_rollout_form(int out_mode, const RolloutArgs &q, unsigned /*g
     if (q.s.B % BLOCK) { r.block0 = n_full; launch_rollout_blocks<Env, PAIRED, false, NOISE>(out_mode, r, 1u, st); }
 }
 
+// nig_rollout's row-major action ring (ld_act == 0): true when EVERY kernel launch_rollout_form<Env, false> starts for this
+// request reads a lane's actions as contiguous bytes -- the LDS-resident PowerGrid body (nig_pg_lds.hpp: wide 512 / 256 and the
+// paired form's LDS stepper).  Mirrors the form selection above, predicate by predicate: whole 256-lane blocks only (a ragged
+// block runs rollout_kernel), an auto-reset handle without held lanes, the wide knob on, and not the paired regime's
+// register-resident stepper (out_mode 0 / 1 below NIG_TUNE_SPLIT_BLOCKS blocks: rollout_body reads rows).
+template <class Env>
+static bool rollout_rows_native(int out_mode, const RolloutArgs &q)
+{
+    if constexpr (wide_rollout<Env>::value == 0 || Env::A != 8) return false;
+    else {
+        constexpr unsigned WB = (unsigned)wide_rollout<Env>::value;
+        const bool plain = (q.s.hflags & NIG_F_AUTORESET) != 0 && (q.s.hflags & HF_MAY_HOLD_DONE) == 0;
+        if (!plain || q.s.wide_min_blocks >= (1u << 30) || q.s.B % BLOCK != 0u || q.s.B == 0u) return false;
+        const unsigned n_full = q.s.B / BLOCK, n_wide = q.s.B / WB;
+        const bool wide = n_wide > 0 && n_wide >= q.s.wide_min_blocks;
+        if constexpr (pair_rollout<Env>::value) {
+            const bool paired = !wide && q.s.split_blocks != 0 && n_full <= q.s.split_blocks;
+            if (paired && out_mode <= 1 && NIG_PG_PAIR_REG) return false;
+        }
+        return true;
+    }
+}
+
 // t0 = launch counter of the call's first step (host-known: rollouts are never graph-captured)
 // the envs the reference can record draws for (ChemicalReactor, PowerGrid, RobotAssembly): nig_rollout_noise
 template <class Env> struct noise_rollout : std::bool_constant<(Env::ID <= 2)> {};
@@ -2168,7 +2193,7 @@ static const EnvLaunch *env_launch_table()
 {
     static const EnvLaunch T = {launch_step<Env>, Env::HAS_ACT64 ? launch_step64<Env> : nullptr, launch_rollout_env<Env>, launch_policy<Env>,
                                 (Env::S % 2 == 0 && Env::A <= 16) ? launch_mlp<Env> : nullptr,
-                                launch_reset<Env>, launch_fill<Env>};
+                                launch_reset<Env>, launch_fill<Env>, rollout_rows_native<Env>};
     return &T;
 }
 

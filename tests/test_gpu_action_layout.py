@@ -69,9 +69,27 @@ def test_powergrid_wide_form_reads_a_row_major_ring_natively(ni, outputs):
     assert used_b < ring_bytes // 2, (used_b, ring_bytes)              # native: the library allocated nothing of ring size
 
 
-@pytest.mark.parametrize("key,B", [("pg", 4096 + 77), ("pg", 768), ("cr", 1024), ("cr", 1000), ("ra", 512)])
+@pytest.mark.parametrize("B,outputs,native", [(768, "aos", True),        # paired form, LDS-resident stepper (trajectory)
+                                              (768, "rows", False),      # paired form, register-resident stepper: rows
+                                              (66048, "rows", True),     # 258 blocks: past the paired regime, wide 256-lane form
+                                              (66048 + 512, "aos", True)])
+def test_powergrid_small_batch_forms_and_the_row_major_ring(ni, B, outputs, native):
+    """PowerGrid below the wide threshold, default knobs: every LDS-resident form reads the row-major slots natively (the
+    launcher's own predicate, rollout_rows_native), the paired regime's register-resident stepper (reward + flags / no outputs)
+    takes the row copy; bit-identical to rows either way."""
+    ni.tune(wide_min_blocks=-1, split_blocks=-1)
+    R = 600 if B < 4096 else 16
+    kw = dict(key="pg", B=B, chunks=[R, 5], outputs=outputs, R=R)
+    a, _, ring_bytes = _run(ni, layout="rows", **kw)
+    b, used_b, _ = _run(ni, layout="aos", **kw)
+    _same(a, b)
+    assert ring_bytes >= (8 << 20)
+    assert (used_b < ring_bytes // 2) == native, (used_b, ring_bytes, native)
+
+
+@pytest.mark.parametrize("key,B", [("pg", 4096 + 77), ("cr", 1024), ("cr", 1000), ("ra", 512)])
 def test_other_forms_take_a_row_major_ring_through_the_row_copy(ni, key, B):
-    """A ragged PowerGrid batch (wide + 256-lane + one-wave launches), a PowerGrid batch below the wide threshold, ChemicalReactor
+    """A ragged PowerGrid batch (wide + 256-lane + one-wave launches), ChemicalReactor
     and RobotAssembly in their three-wave and one-wave forms: the library transposes the ring into rows it owns (a ring-sized
     allocation appears: the slots a call reads, min(ring_len, n_steps) of them), results equal the rows' bit for bit; a second
     call reuses the buffer."""
