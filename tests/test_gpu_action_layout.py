@@ -56,12 +56,13 @@ def _same(a, b):
         assert x.shape == y.shape and torch.equal(xv, yv), f"observable {i} differs"
 
 
+@pytest.mark.parametrize("B", [4096, 4096 + 256])            # eight wide blocks; eight wide blocks + one 256-lane block (two launches)
 @pytest.mark.parametrize("outputs", ["none", "rows", "aos"])
-def test_powergrid_wide_form_reads_a_row_major_ring_natively(ni, outputs):
+def test_powergrid_wide_form_reads_a_row_major_ring_natively(ni, outputs, B):
     """Whole 512-lane blocks in the wide form (knob at one block): chained launches with ring wrap, truncations, terminations and
     in-kernel resets; row-major ring == rows, and no ring-sized allocation appears on the device."""
     ni.tune(wide_min_blocks=1, split_blocks=0)
-    kw = dict(key="pg", B=4096, chunks=[200, 9], outputs=outputs, R=512)         # 512 slots x 8 x 4096 x 4 B = 64 MiB ring, 200 of them read
+    kw = dict(key="pg", B=B, chunks=[200, 9], outputs=outputs, R=512)            # 512 slots x 8 x 4096 x 4 B = 64 MiB ring, 200 of them read
     a, used_a, ring_bytes = _run(ni, layout="rows", **kw)
     b, used_b, _ = _run(ni, layout="aos", **kw)
     _same(a, b)
