@@ -1712,6 +1712,9 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
         // chunk boundary: every wave's share of the fill has landed (the compiler drains vmcnt before the barrier)
         // and every wave is done with the buffer the next fill overwrites
         __syncthreads();
+#if defined(NIG_DIAG_MLP_SKIP) && (NIG_DIAG_MLP_SKIP & 2)
+        if (it == 0)
+#endif
         fill(1, gbuf ^ 1, MLP_PIECES);
         f32x16 h1[MLP_MT];
         {
@@ -1736,8 +1739,14 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
         constexpr int RING = 8;                             // LDS reads in flight ahead of their MFMA (~64 cycles apart)
         for (int m2 = 0; m2 < MLP_MT; ++m2) {               // a real loop: the body is 145 MFMAs of straight-line code
             __syncthreads();                                // chunk 1 + m2 is in s_w[gbuf]; s_w[gbuf ^ 1] is free
+#if defined(NIG_DIAG_MLP_SKIP) && (NIG_DIAG_MLP_SKIP & 2)     // (diagnostic, WRONG results: no LDS-DMA traffic after the first step)
+            if (it == 0) {
+#endif
             if (m2 + 1 < MLP_MT) fill(2 + m2, gbuf ^ 1, MLP_PIECES);
             else if (it + 1 < q.n_steps) fill(0, gbuf ^ 1, PIECES0);   // layer 1 of the NEXT step (the weights do not change)
+#if defined(NIG_DIAG_MLP_SKIP) && (NIG_DIAG_MLP_SKIP & 2)
+            }
+#endif
             const float *wb = &s_w[gbuf][lane];
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             float ring[RING];
@@ -1783,6 +1792,11 @@ __global__ void __launch_bounds__(BLOCK, mlp_two_blocks<Env> ? 2 : 1) rollout_ml
             }
         }
 
+#if defined(NIG_DIAG_MLP_SKIP) && (NIG_DIAG_MLP_SKIP & 1)     // (diagnostic builds only, WRONG results: the actor without the env step)
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = __builtin_fmaf(1e-9f, a[k % A], s[k]);
+        continue;
+#endif
         // ---------------- IndustrialEnv.step (both lane halves, identical results) ----------------
         const uint32_t orow = (uint32_t)it * q.out_stride;
         const bool frozen = (ctr & NIG_CTR_DONE) != 0;
