@@ -1274,7 +1274,7 @@ void oracle_rollout(int env, int64_t n, uint64_t env0, uint64_t seed, uint32_t t
 #pragma omp for schedule(static)
 #endif
         for (int64_t i = 0; i < n; i++) {
-            float s[32], nx[32], a[12];
+            float s[32], nx[32], a[16];
             double nz[32];
             uint64_t gi = env0 + (uint64_t)i;
             int step;
@@ -1528,7 +1528,7 @@ void oracle_rollout_mlp(int env, int64_t n, uint64_t env0, uint64_t seed, uint32
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int64_t i = 0; i < n; i++) {
-        float s[32], nx[32], a[12];
+        float s[32], nx[32], a[16];
         double nz[32];
         uint64_t gi = env0 + (uint64_t)i;
         oracle_tally_t me; memset(&me, 0, sizeof me);
